@@ -1,0 +1,241 @@
+"""ctypes binding of libdpk_gfx950.so (include/dpk.h) — the only compute backend of this package.
+
+There is deliberately no CPU or PyTorch fallback: if the shared library is missing, or a tensor
+is not a CUDA(HIP) fp32 tensor, the call raises.  The wrappers check on the host that operand
+shapes match what each kernel's grid assumes before anything is launched.
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+from ctypes import c_char_p, c_float, c_int, c_int64, c_uint64, c_void_p
+from typing import Optional
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_NAME = "libdpk_gfx950.so"
+LIB_PATH = os.path.join(_HERE, LIB_NAME)
+
+EXPORTS = {
+    # name: (restype, argtypes)
+    "dpk_version": (c_int, []),
+    "dpk_error_string": (c_char_p, [c_int]),
+    "dpk_linear_slots": (c_int, [c_int, c_int]),
+    "dpk_embedding_slots": (c_int, [c_int, c_int]),
+    "dpk_layernorm_slots": (c_int, [c_int]),
+    "dpk_normsq_slots": (c_int, [c_int64]),
+    "dpk_linear_grad_sample": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int,
+                                       c_int, c_int, c_int, c_int, c_int64, c_float, c_void_p]),
+    "dpk_embedding_grad_sample": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int,
+                                          c_int, c_int, c_int, c_int, c_int64, c_float, c_void_p]),
+    "dpk_layernorm_grad_sample": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int,
+                                          c_int, c_int, c_int, c_float, c_int64, c_float, c_void_p]),
+    "dpk_normsq_partials": (c_int, [c_void_p, c_int64, c_void_p, c_int64, c_int, c_int, c_int64, c_void_p]),
+    "dpk_clip_factors": (c_int, [c_void_p, c_int64, c_int, c_void_p, c_void_p, c_int, c_float, c_void_p]),
+    "dpk_clip_reduce_workspace": (c_int64, [c_int, c_int64]),
+    "dpk_clip_reduce": (c_int, [c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_int, c_int64, c_void_p,
+                                c_int64, c_void_p]),
+    "dpk_noise_scale": (c_int, [c_void_p, c_void_p, c_uint64, c_uint64, c_float, c_float, c_void_p, c_int64,
+                                c_void_p]),
+    "dpk_clip_reduce_noise": (c_int, [c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_uint64, c_uint64,
+                                      c_float, c_float, c_void_p, c_void_p, c_int, c_int64, c_void_p, c_int64,
+                                      c_void_p]),
+    "dpk_philox_normal": (c_int, [c_void_p, c_int64, c_uint64, c_uint64, c_float, c_void_p]),
+}
+
+
+class DpkError(RuntimeError):
+    pass
+
+
+_lib = None
+
+
+def load() -> ctypes.CDLL:
+    """Load the HIP extension; raises (loudly) if it has not been built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise DpkError(
+            f"{LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            "(hipcc --offload-arch=gfx950). This package has no CPU fallback.")
+    lib = ctypes.CDLL(LIB_PATH)
+    for name, (res, args) in EXPORTS.items():
+        fn = getattr(lib, name)  # AttributeError if a declared symbol is missing
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def _check(rc: int, what: str):
+    if rc != 0:
+        msg = load().dpk_error_string(rc).decode()
+        raise DpkError(f"{what} failed: {msg} (code {rc})")
+
+
+def _ptr(t: Optional[torch.Tensor]):
+    return None if t is None else c_void_p(t.data_ptr())
+
+
+def _req(t: torch.Tensor, name: str, dtype=torch.float32):
+    if not isinstance(t, torch.Tensor) or not t.is_cuda:
+        raise DpkError(f"{name}: expected a CUDA/HIP tensor (this package has no CPU path)")
+    if t.dtype != dtype:
+        raise DpkError(f"{name}: expected dtype {dtype}, got {t.dtype}")
+
+
+def _stream():
+    return c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+class FlatView:
+    """A [B, n] strided window into the per-sample-gradient arena: base tensor + column offset."""
+
+    __slots__ = ("base", "offset", "numel")
+
+    def __init__(self, base: torch.Tensor, offset: int, numel: int):
+        assert base.dim() == 2 and base.stride(1) == 1
+        assert 0 <= offset and offset + numel <= base.shape[1]
+        self.base, self.offset, self.numel = base, offset, numel
+
+    @property
+    def ptr(self):
+        return c_void_p(self.base.data_ptr() + 4 * self.offset)
+
+    @property
+    def stride(self):
+        return self.base.stride(0)
+
+
+# ---- thin, shape-checked wrappers ---------------------------------------------------------------
+
+
+def linear_slots(in_f: int, out_f: int) -> int:
+    return load().dpk_linear_slots(in_f, out_f)
+
+
+def normsq_slots(P: int) -> int:
+    return load().dpk_normsq_slots(P)
+
+
+def linear_grad_sample(A, G, gs_w: FlatView, gs_b: Optional[FlatView], part: torch.Tensor, slot0: int,
+                       g_scale: float):
+    _req(A, "A"); _req(G, "G"); _req(part, "normsq_part"); _req(gs_w.base, "arena")
+    if A.dim() != 3 or G.dim() != 3 or not A.is_contiguous() or not G.is_contiguous():
+        raise DpkError("A and G must be contiguous [B,T,features]")
+    B, T, in_f = A.shape
+    if G.shape[0] != B or G.shape[1] != T:
+        raise DpkError(f"A {tuple(A.shape)} and G {tuple(G.shape)} disagree on [B,T]")
+    out_f = G.shape[2]
+    if gs_w.numel != in_f * out_f or (gs_b is not None and gs_b.numel != out_f):
+        raise DpkError("grad-sample window does not match the layer shape")
+    if gs_w.base.shape[0] < B or part.shape[0] < B or part.dim() != 2 or part.stride(1) != 1:
+        raise DpkError("arena / partial buffer has fewer rows than the batch")
+    if gs_b is not None and gs_b.base.data_ptr() != gs_w.base.data_ptr():
+        raise DpkError("weight and bias windows must live in the same arena")
+    rc = load().dpk_linear_grad_sample(_ptr(A), _ptr(G), gs_w.ptr, None if gs_b is None else gs_b.ptr,
+                                       _ptr(part), part.stride(0), slot0, B, T, in_f, out_f, gs_w.stride,
+                                       float(g_scale), _stream())
+    _check(rc, "dpk_linear_grad_sample")
+
+
+def embedding_grad_sample(idx, G, gs: FlatView, V: int, part: torch.Tensor, slot0: int, g_scale: float):
+    _req(idx, "idx", torch.int64); _req(G, "G"); _req(part, "normsq_part")
+    if idx.dim() != 2 or G.dim() != 3 or not idx.is_contiguous() or not G.is_contiguous():
+        raise DpkError("idx must be contiguous [B,T] and G contiguous [B,T,E]")
+    B, T = idx.shape
+    E = G.shape[2]
+    if G.shape[0] != B or G.shape[1] != T or gs.numel != V * E:
+        raise DpkError("embedding grad-sample shapes disagree")
+    if gs.base.shape[0] < B or part.shape[0] < B:
+        raise DpkError("arena / partial buffer has fewer rows than the batch")
+    rc = load().dpk_embedding_grad_sample(_ptr(idx), _ptr(G), gs.ptr, _ptr(part), part.stride(0), slot0, B, T, V, E,
+                                          gs.stride, float(g_scale), _stream())
+    _check(rc, "dpk_embedding_grad_sample")
+
+
+def layernorm_grad_sample(X, G, gs_w: FlatView, gs_b: FlatView, part: torch.Tensor, slot0: int, eps: float,
+                          g_scale: float):
+    _req(X, "X"); _req(G, "G"); _req(part, "normsq_part")
+    if X.dim() != 3 or X.shape != G.shape or not X.is_contiguous() or not G.is_contiguous():
+        raise DpkError("X and G must be contiguous [B,T,C] of equal shape")
+    B, T, C = X.shape
+    if gs_w.numel != C or gs_b.numel != C or gs_w.base.shape[0] < B or part.shape[0] < B:
+        raise DpkError("layernorm grad-sample shapes disagree")
+    rc = load().dpk_layernorm_grad_sample(_ptr(X), _ptr(G), gs_w.ptr, gs_b.ptr, _ptr(part), part.stride(0), slot0,
+                                          B, T, C, float(eps), gs_w.stride, float(g_scale), _stream())
+    _check(rc, "dpk_layernorm_grad_sample")
+
+
+def normsq_partials(gs: FlatView, B: int, part: torch.Tensor, slot0: int):
+    _req(gs.base, "GS"); _req(part, "normsq_part")
+    if gs.base.shape[0] < B or part.shape[0] < B:
+        raise DpkError("arena / partial buffer has fewer rows than the batch")
+    rc = load().dpk_normsq_partials(gs.ptr, gs.stride, _ptr(part), part.stride(0), slot0, B, gs.numel, _stream())
+    _check(rc, "dpk_normsq_partials")
+
+
+def clip_factors(part: torch.Tensor, n_slots: int, clip: torch.Tensor, norms: Optional[torch.Tensor], B: int,
+                 max_grad_norm: float):
+    _req(part, "normsq_part"); _req(clip, "clip")
+    if part.shape[0] < B or clip.numel() < B or (norms is not None and norms.numel() < B) or n_slots > part.shape[1]:
+        raise DpkError("clip_factors: buffers shorter than the batch / slots")
+    rc = load().dpk_clip_factors(_ptr(part), part.stride(0), n_slots, _ptr(clip), _ptr(norms), B,
+                                 float(max_grad_norm), _stream())
+    _check(rc, "dpk_clip_factors")
+
+
+def clip_reduce_workspace(B: int, P: int) -> int:
+    return int(load().dpk_clip_reduce_workspace(B, P))
+
+
+def _ws_args(workspace: Optional[torch.Tensor]):
+    if workspace is None:
+        return None, 0
+    return _ptr(workspace), workspace.numel() * workspace.element_size()
+
+
+def clip_reduce(gs: FlatView, clip, summed_in, summed_out, B: int, workspace=None):
+    _req(gs.base, "GS"); _req(clip, "clip"); _req(summed_out, "summed_out")
+    P = gs.numel
+    if clip.numel() < B or gs.base.shape[0] < B or summed_out.numel() < P or (summed_in is not None and summed_in.numel() < P):
+        raise DpkError("clip_reduce: buffers shorter than [B] / [P]")
+    wp, wb = _ws_args(workspace)
+    rc = load().dpk_clip_reduce(gs.ptr, gs.stride, _ptr(clip), _ptr(summed_in), _ptr(summed_out), B, P, wp, wb,
+                                _stream())
+    _check(rc, "dpk_clip_reduce")
+
+
+def noise_scale(summed, noise, seed: int, offset: int, noise_std: float, inv_scale: float, grad, P: int):
+    _req(grad, "grad")
+    if grad.numel() < P or (summed is not None and summed.numel() < P) or (noise is not None and noise.numel() < P):
+        raise DpkError("noise_scale: buffers shorter than P")
+    rc = load().dpk_noise_scale(_ptr(summed), _ptr(noise), seed & (2**64 - 1), offset & (2**64 - 1),
+                                float(noise_std), float(inv_scale), _ptr(grad), P, _stream())
+    _check(rc, "dpk_noise_scale")
+
+
+def clip_reduce_noise(gs: FlatView, clip, summed_in, noise, seed: int, offset: int, noise_std: float,
+                      inv_scale: float, summed_out, grad, B: int, workspace=None):
+    _req(gs.base, "GS"); _req(clip, "clip"); _req(grad, "grad")
+    P = gs.numel
+    for t, n in ((summed_in, "summed_in"), (noise, "noise"), (summed_out, "summed_out"), (grad, "grad")):
+        if t is not None and t.numel() < P:
+            raise DpkError(f"clip_reduce_noise: {n} shorter than P")
+    if clip.numel() < B or gs.base.shape[0] < B:
+        raise DpkError("clip_reduce_noise: buffers shorter than the batch")
+    wp, wb = _ws_args(workspace)
+    rc = load().dpk_clip_reduce_noise(gs.ptr, gs.stride, _ptr(clip), _ptr(summed_in), _ptr(noise),
+                                      seed & (2**64 - 1), offset & (2**64 - 1), float(noise_std), float(inv_scale),
+                                      _ptr(summed_out), _ptr(grad), B, P, wp, wb, _stream())
+    _check(rc, "dpk_clip_reduce_noise")
+
+
+def philox_normal(out: torch.Tensor, seed: int, offset: int, std: float):
+    _req(out, "out")
+    rc = load().dpk_philox_normal(_ptr(out), out.numel(), seed & (2**64 - 1), offset & (2**64 - 1), float(std),
+                                  _stream())
+    _check(rc, "dpk_philox_normal")

@@ -1,0 +1,144 @@
+/*
+ * dpk.h — C ABI of libdpk_gfx950.so: the MI355X (gfx950 / CDNA4) kernels of the DP-SGD step.
+ *
+ * The reference (ammanyusuf/dp-timeautodiff) is pure Python and has no FFI of its own: every
+ * arithmetic step below is what Opacus dispatches to ATen when the reference executes
+ *     loss_Auto.backward()   Model_Code/timeautoencoder.py:749   (per-sample gradients, hooks)
+ *     optimizer_ae.step()    Model_Code/timeautoencoder.py:751   (clip -> sum -> noise -> scale)
+ * Each entry point cites the Opacus operation and the reference call site
+ * it replaces.  The Python host (dp_timeautodiff_amd/) binds these with ctypes; the binding a
+ * maintainer would add is shown in INTEGRATION.md.
+ *
+ * Conventions
+ *   - plain C types only; pointers are DEVICE pointers (hipMalloc / torch.Tensor.data_ptr()),
+ *     fp32 row-major, contiguous unless a stride argument says otherwise;
+ *   - `stream` is a hipStream_t passed as void* (torch.cuda.current_stream().cuda_stream);
+ *     every call is asynchronous and stream-ordered, allocates nothing, keeps no global state;
+ *   - return 0 on success, a negative DPK_E* code on an argument error (nothing launched), or a
+ *     positive hipError_t if the launch failed.  Nothing throws.
+ *   - per-sample squared norms are produced as *partials*: every grad-sample kernel writes, for
+ *     sample b, `slots` floats at normsq_part[b*part_stride + slot0 ... ]; dpk_clip_factors sums a
+ *     sample's slots in index order.  No float atomics anywhere: results are bitwise reproducible
+ *     run to run.
+ */
+#ifndef DPK_H
+#define DPK_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define DPK_VERSION 100 /* 0.1.0 */
+
+#define DPK_OK 0
+#define DPK_EINVAL (-1)   /* null pointer / non-positive dimension / bad flag */
+#define DPK_ERANGE (-2)   /* dimension beyond what the kernel's grid or LDS plan supports */
+#define DPK_EALIGN (-3)   /* pointer or stride not aligned as documented */
+#define DPK_ESLOTS (-4)   /* normsq partial row too short for the slots this call writes */
+
+int dpk_version(void);
+const char* dpk_error_string(int code);
+
+/* Number of normsq partial slots the corresponding *_grad_sample call writes per sample. */
+int dpk_linear_slots(int in_features, int out_features);
+int dpk_embedding_slots(int num_embeddings, int embedding_dim);
+int dpk_layernorm_slots(int channels);
+int dpk_normsq_slots(int64_t P);
+
+/*
+ * K1 — per-sample gradient of nn.Linear / RNNLinear (batched fp32 MFMA GEMM, K = T).
+ * Replaces Opacus' Linear grad sampler  einsum("n...i,n...j->nij", backprops, activations)  and
+ * einsum("n...k->nk", backprops), applied once per layer *call* and accumulated T times for the
+ * CustomGRU gates (timeautoencoder.py:84-94 via :749).  Here the T calls are stacked by the host
+ * and contracted in one launch:
+ *     GSw[b,o,i] = sum_t (g_scale*G[b,t,o]) * A[b,t,i]        GSb[b,o] = sum_t g_scale*G[b,t,o]
+ * A [B,T,in], G [B,T,out] contiguous.  GSw/GSb rows of sample b start at b*gs_stride floats
+ * (gs_stride = row length of the flat per-sample-gradient arena).  GSb may be NULL (no bias).
+ * g_scale = batch size for loss_reduction="mean" (Opacus multiplies backprops by n first; so do we).
+ * Writes dpk_linear_slots(in,out) normsq partials per sample, covering weight and bias.
+ */
+int dpk_linear_grad_sample(const float* A, const float* G, float* GSw, float* GSb,
+                           float* normsq_part, int64_t part_stride, int slot0,
+                           int B, int T, int in_features, int out_features,
+                           int64_t gs_stride, float g_scale, void* stream);
+
+/*
+ * K3 — per-sample gradient of nn.Embedding.  Replaces Opacus' Embedding sampler
+ *     zeros(B,V,E).scatter_add_(1, index, backprops)     (Embedding_data, timeautoencoder.py:128-133,160-164)
+ * idx [B,T] int64 (values in [0,V)), G [B,T,E]; GS[b,v,:] = sum_{t: idx[b,t]=v} g_scale*G[b,t,:], summed in
+ * increasing t.  Out-of-range indices are ignored (the forward would already have raised).
+ */
+int dpk_embedding_grad_sample(const int64_t* idx, const float* G, float* GS,
+                              float* normsq_part, int64_t part_stride, int slot0,
+                              int B, int T, int V, int E,
+                              int64_t gs_stride, float g_scale, void* stream);
+
+/*
+ * K4 — per-sample gradient of nn.LayerNorm over the last dim.  Replaces Opacus' LayerNorm sampler
+ *     sum_t(F.layer_norm(x, (C,), eps=eps) * backprops), sum_t(backprops)      (timediffusion.py:107)
+ * X, G [B,T,C]; GSw[b,c], GSb[b,c].
+ */
+int dpk_layernorm_grad_sample(const float* X, const float* G, float* GSw, float* GSb,
+                              float* normsq_part, int64_t part_stride, int slot0,
+                              int B, int T, int C, float eps,
+                              int64_t gs_stride, float g_scale, void* stream);
+
+/*
+ * K5 — squared-norm partials of externally produced per-sample gradients (a [B,P] strided matrix),
+ * for grads that did not come from K1/K3/K4.  Replaces  g.reshape(len(g),-1).norm(2,dim=-1)  of
+ * DPOptimizer.clip_and_accumulate (timeautoencoder.py:751).  Writes dpk_normsq_slots(P) partials.
+ */
+int dpk_normsq_partials(const float* GS, int64_t gs_stride, float* normsq_part, int64_t part_stride,
+                        int slot0, int B, int64_t P, void* stream);
+
+/*
+ * K6 — per-sample norm and clip factor.  Replaces
+ *     per_sample_norms = stack(per_param_norms).norm(2, dim=1)
+ *     per_sample_clip_factor = (max_grad_norm / (per_sample_norms + 1e-6)).clamp(max=1.0)
+ * normsq_part [B, part_stride]: slots [0, n_slots) of each row are summed in index order.
+ * norms (nullable) receives sqrt(sum); clip receives the factor.
+ */
+int dpk_clip_factors(const float* normsq_part, int64_t part_stride, int n_slots,
+                     float* clip, float* norms, int B, float max_grad_norm, void* stream);
+
+/*
+ * K7a — clipped weighted sum over the batch.  Replaces  einsum("i,i...", clip, grad_sample)  per
+ * parameter and the `p.summed_grad (+)= grad` accumulation, as ONE launch over the whole flat arena:
+ *     summed_out[j] = (summed_in ? summed_in[j] : 0) + sum_b clip[b] * GS[b*gs_stride + j],  j in [0,P)
+ * P and gs_stride must be multiples of 4 and all pointers 16-byte aligned (the arena guarantees it).
+ * Reads every per-sample gradient element exactly once.  `workspace` (>= dpk_clip_reduce_workspace
+ * bytes; may be NULL when that returns 0) holds split-B partial sums; summed_in may alias summed_out.
+ */
+int64_t dpk_clip_reduce_workspace(int B, int64_t P);
+int dpk_clip_reduce(const float* GS, int64_t gs_stride, const float* clip, const float* summed_in,
+                    float* summed_out, int B, int64_t P, void* workspace, int64_t workspace_bytes,
+                    void* stream);
+
+/*
+ * K7b — add_noise + scale_grad.  Replaces
+ *     p.grad = p.summed_grad + normal(0, noise_multiplier*max_grad_norm)      (add_noise)
+ *     p.grad /= expected_batch_size * accumulated_iterations                  (scale_grad)
+ * grad[j] = (summed[j] + z[j]) * inv_scale.  z = noise[j] if `noise` is non-NULL (injected tensor,
+ * already scaled by std — the parity path), else noise_std * Philox4x32-10 normal #j of the stream
+ * (seed, offset): element j uses Philox block (offset + j/4), lane j%4 — every rank of a data-parallel
+ * job draws the same z from the same (seed, offset).  noise_std == 0 and noise == NULL -> z = 0.
+ */
+int dpk_noise_scale(const float* summed, const float* noise, uint64_t seed, uint64_t offset,
+                    float noise_std, float inv_scale, float* grad, int64_t P, void* stream);
+
+/* K7 fused = K7a followed by K7b without the intermediate P-sized round trip (single-GPU path).
+ * summed_out (nullable) additionally receives the un-noised clipped sum. */
+int dpk_clip_reduce_noise(const float* GS, int64_t gs_stride, const float* clip, const float* summed_in,
+                          const float* noise, uint64_t seed, uint64_t offset, float noise_std,
+                          float inv_scale, float* summed_out, float* grad, int B, int64_t P,
+                          void* workspace, int64_t workspace_bytes, void* stream);
+
+/* Philox normal stream on its own (tests; also lets host code pre-draw the shared noise). */
+int dpk_philox_normal(float* out, int64_t n, uint64_t seed, uint64_t offset, float std, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* DPK_H */

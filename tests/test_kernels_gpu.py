@@ -1,0 +1,276 @@
+"""Parity of every HIP kernel (through the C-ABI) against the CPU oracle.  GPU only."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import rel_err
+
+pytestmark = pytest.mark.gpu
+
+TOL = 1e-5
+
+
+@pytest.fixture(scope="module")
+def nat():
+    assert torch.cuda.is_available(), "GPU tests need a GPU"
+    from dp_timeautodiff_amd import _native
+    _native.load()
+    return _native
+
+
+def _arena(B, width, pad_front=64, pad_back=64):
+    stride = pad_front + width + pad_back
+    stride = (stride + 3) // 4 * 4
+    base = torch.zeros(B, stride, device="cuda", dtype=torch.float32)
+    return base, pad_front
+
+
+LINEAR_SHAPES = [
+    # (B, T, in, out)
+    (3, 24, 400, 200), (8, 24, 208, 208), (5, 24, 13, 200), (4, 24, 200, 7), (7, 24, 7, 200),
+    (2, 24, 128, 13), (9, 48, 1, 125), (3, 48, 1000, 250), (2, 48, 500, 7), (4, 5, 8, 32),
+    (1, 1, 33, 65), (6, 7, 80, 80), (2, 70, 96, 40), (3, 256, 160, 96), (16, 3, 64, 64),
+]
+
+
+@pytest.mark.parametrize("B,T,in_f,out_f", LINEAR_SHAPES)
+@pytest.mark.parametrize("bias", [True, False])
+def test_linear_grad_sample(nat, B, T, in_f, out_f, bias):
+    from oracle import opacus_ref as O
+    g = torch.Generator().manual_seed(B * 1000 + T * 7 + in_f + out_f)
+    A = torch.randn(B, T, in_f, generator=g)
+    G = torch.randn(B, T, out_f, generator=g) * 0.01
+    scale = float(B)
+    gw_ref, gb_ref = O.linear_grad_sample(A, G * scale, bias)
+    nw = in_f * out_f
+    base, off = _arena(B, nw + out_f)
+    slots = nat.linear_slots(in_f, out_f)
+    part = torch.full((B, slots + 3), -1.0, device="cuda")
+    vw = nat.FlatView(base, off, nw)
+    vb = nat.FlatView(base, off + nw, out_f) if bias else None
+    nat.linear_grad_sample(A.cuda(), G.cuda(), vw, vb, part, 2, scale)
+    torch.cuda.synchronize()
+    out = base.cpu()
+    gw = out[:, off:off + nw].reshape(B, out_f, in_f)
+    assert rel_err(gw.numpy(), gw_ref.numpy()) < TOL
+    ref_sq = (gw_ref.double() ** 2).sum((1, 2))
+    if bias:
+        gb = out[:, off + nw:off + nw + out_f]
+        assert rel_err(gb.numpy(), gb_ref.numpy()) < TOL
+        ref_sq = ref_sq + (gb_ref.double() ** 2).sum(1)
+    else:
+        assert (out[:, off + nw:] == 0).all()
+    # pads untouched
+    assert (out[:, :off] == 0).all() and (out[:, off + nw + out_f:] == 0).all()
+    p = part.cpu()
+    assert (p[:, :2] == -1).all() and (p[:, 2 + slots:] == -1).all()
+    assert rel_err(p[:, 2:2 + slots].double().sum(1).numpy(), ref_sq.numpy()) < TOL
+
+
+def test_linear_grad_sample_is_deterministic(nat):
+    g = torch.Generator().manual_seed(5)
+    A = torch.randn(16, 24, 400, generator=g).cuda()
+    G = torch.randn(16, 24, 200, generator=g).cuda()
+    outs = []
+    for _ in range(3):
+        base, off = _arena(16, 400 * 200 + 200)
+        part = torch.zeros(16, nat.linear_slots(400, 200), device="cuda")
+        nat.linear_grad_sample(A, G, nat.FlatView(base, off, 80000), nat.FlatView(base, off + 80000, 200), part, 0, 16.0)
+        outs.append((base.cpu(), part.cpu()))
+    for o in outs[1:]:
+        assert torch.equal(o[0], outs[0][0]) and torch.equal(o[1], outs[0][1])
+
+
+@pytest.mark.parametrize("case", ["vae_small_mixed.npz", "vae_small_nums.npz", "denoiser_small.npz"])
+def test_stacked_calls_match_reference_autograd(nat, golden, case):
+    """T calls of one Linear stacked into one K=T contraction == the reference's per-sample grads."""
+    g = golden(case)
+    B = g.meta["B"]
+    n = 0
+    for lname, ncalls in g.layers.items():
+        if not g.has(f"gs/{lname}.weight") or g[f"A/{lname}/0"].dtype.kind == "i" or "layer_norm" in lname:
+            continue
+        As = [torch.from_numpy(g[f"A/{lname}/{k}"]) for k in range(ncalls)]
+        Gs = [torch.from_numpy(g[f"G/{lname}/{k}"]) for k in range(ncalls)]
+        if As[0].dim() == 2:
+            A = torch.stack(As, 1)
+            G = torch.stack(Gs, 1)
+        else:
+            A = torch.cat(As, 1)
+            G = torch.cat(Gs, 1)
+        in_f, out_f = A.shape[-1], G.shape[-1]
+        base, off = _arena(B, in_f * out_f + out_f)
+        part = torch.zeros(B, nat.linear_slots(in_f, out_f), device="cuda")
+        nat.linear_grad_sample(A.contiguous().cuda(), G.contiguous().cuda(), nat.FlatView(base, off, in_f * out_f),
+                               nat.FlatView(base, off + in_f * out_f, out_f), part, 0, float(B))
+        out = base.cpu().numpy()
+        assert rel_err(out[:, off:off + in_f * out_f].reshape(B, out_f, in_f), g[f"gs/{lname}.weight"]) < TOL, lname
+        assert rel_err(out[:, off + in_f * out_f:off + in_f * out_f + out_f], g[f"gs/{lname}.bias"]) < TOL, lname
+        n += 1
+    assert n >= 7
+
+
+@pytest.mark.parametrize("B,T,V,E", [(8, 6, 5, 8), (4, 24, 48, 128), (3, 24, 3, 128), (5, 1, 2, 7), (2, 300, 18, 33)])
+def test_embedding_grad_sample(nat, B, T, V, E):
+    from oracle import opacus_ref as O
+    g = torch.Generator().manual_seed(B + T + V + E)
+    idx = torch.randint(0, V, (B, T), generator=g)
+    G = torch.randn(B, T, E, generator=g)
+    ref = O.embedding_grad_sample(idx, G * float(B), V)
+    base, off = _arena(B, V * E)
+    part = torch.zeros(B, 1, device="cuda")
+    nat.embedding_grad_sample(idx.cuda(), G.cuda(), nat.FlatView(base, off, V * E), V, part, 0, float(B))
+    out = base.cpu()
+    assert rel_err(out[:, off:off + V * E].reshape(B, V, E).numpy(), ref.numpy()) < TOL
+    assert (out[:, :off] == 0).all() and (out[:, off + V * E:] == 0).all()
+    assert rel_err(part.cpu()[:, 0].numpy(), (ref.double() ** 2).sum((1, 2)).numpy()) < TOL
+
+
+def test_embedding_golden(nat, golden):
+    g = golden("vae_small_mixed.npz")
+    B = g.meta["B"]
+    for k in range(3):
+        lname = f"Emb.embeddings_list.{k}"
+        idx = torch.from_numpy(g[f"A/{lname}/0"])
+        G = torch.from_numpy(g[f"G/{lname}/0"])
+        ref = g[f"gs/{lname}.weight"]
+        V, E = ref.shape[1:]
+        base, off = _arena(B, V * E)
+        part = torch.zeros(B, 1, device="cuda")
+        nat.embedding_grad_sample(idx.cuda(), G.cuda(), nat.FlatView(base, off, V * E), V, part, 0, float(B))
+        assert rel_err(base.cpu()[:, off:off + V * E].reshape(B, V, E).numpy(), ref) < TOL
+
+
+@pytest.mark.parametrize("B,T,C", [(6, 5, 16), (4, 48, 500), (3, 300, 70), (2, 1, 1000)])
+def test_layernorm_grad_sample(nat, B, T, C):
+    from oracle import opacus_ref as O
+    g = torch.Generator().manual_seed(B + T + C)
+    X = torch.randn(B, T, C, generator=g) * 2 + 0.5
+    G = torch.randn(B, T, C, generator=g)
+    gw_ref, gb_ref = O.layernorm_grad_sample(X, G * float(B), (C,), 1e-5)
+    base, off = _arena(B, 2 * C)
+    part = torch.zeros(B, 1, device="cuda")
+    nat.layernorm_grad_sample(X.cuda(), G.cuda(), nat.FlatView(base, off, C), nat.FlatView(base, off + C, C), part, 0,
+                              1e-5, float(B))
+    out = base.cpu()
+    assert rel_err(out[:, off:off + C].numpy(), gw_ref.numpy()) < TOL
+    assert rel_err(out[:, off + C:off + 2 * C].numpy(), gb_ref.numpy()) < TOL
+    ref_sq = (gw_ref.double() ** 2).sum(1) + (gb_ref.double() ** 2).sum(1)
+    assert rel_err(part.cpu()[:, 0].numpy(), ref_sq.numpy()) < TOL
+
+
+def test_layernorm_golden(nat, golden):
+    g = golden("denoiser_small.npz")
+    B = g.meta["B"]
+    X = torch.from_numpy(g["A/layer_norm/0"])
+    G = torch.from_numpy(g["G/layer_norm/0"])
+    C = X.shape[-1]
+    base, off = _arena(B, 2 * C)
+    part = torch.zeros(B, 1, device="cuda")
+    nat.layernorm_grad_sample(X.cuda(), G.cuda(), nat.FlatView(base, off, C), nat.FlatView(base, off + C, C), part, 0,
+                              1e-5, float(B))
+    out = base.cpu().numpy()
+    assert rel_err(out[:, off:off + C], g["gs/layer_norm.weight"]) < TOL
+    assert rel_err(out[:, off + C:off + 2 * C], g["gs/layer_norm.bias"]) < TOL
+
+
+@pytest.mark.parametrize("B,P", [(5, 100), (3, 8192), (4, 20001), (2, 649400)])
+def test_normsq_partials_and_clip_factors(nat, B, P):
+    g = torch.Generator().manual_seed(P)
+    GS = torch.randn(B, P, generator=g) * 0.01
+    Pp = (P + 3) // 4 * 4
+    base = torch.zeros(B, Pp + 8, device="cuda")
+    base[:, 4:4 + P] = GS.cuda()
+    slots = nat.normsq_slots(P)
+    part = torch.zeros(B, slots, device="cuda")
+    nat.normsq_partials(nat.FlatView(base, 4, P), B, part, 0)
+    clip = torch.zeros(B, device="cuda")
+    norms = torch.zeros(B, device="cuda")
+    ref_n = GS.double().norm(2, dim=1)
+    C = float(ref_n.median())
+    nat.clip_factors(part, slots, clip, norms, B, C)
+    assert rel_err(norms.cpu().numpy(), ref_n.numpy()) < TOL
+    ref_c = (C / (ref_n + 1e-6)).clamp(max=1.0)
+    assert rel_err(clip.cpu().numpy(), ref_c.numpy()) < TOL
+
+
+@pytest.mark.parametrize("B,P", [(8, 64), (64, 4096), (50, 649400), (200, 10000), (1000, 2048), (1, 12), (33, 100000)])
+@pytest.mark.parametrize("fused", [True, False])
+def test_clip_reduce_noise(nat, B, P, fused):
+    from oracle import opacus_ref as O
+    g = torch.Generator().manual_seed(B * 31 + P)
+    GS = torch.randn(B, P, generator=g)
+    clip = torch.rand(B, generator=g)
+    summed_in = torch.randn(P, generator=g)
+    noise = torch.randn(P, generator=g) * 0.3
+    stride = P + 16
+    base = torch.zeros(B, stride, device="cuda")
+    base[:, 8:8 + P] = GS.cuda()
+    ws_bytes = nat.clip_reduce_workspace(B, P)
+    ws = torch.empty(max(ws_bytes // 4, 4), device="cuda") if ws_bytes else None
+    view = nat.FlatView(base, 8, P)
+    ebs = 49.0
+    ref_sum = torch.einsum("i,ij->j", clip.double(), GS.double()) + summed_in.double()
+    ref_grad = (ref_sum + noise.double()) / ebs
+    summed = torch.zeros(P, device="cuda")
+    grad = torch.zeros(P, device="cuda")
+    if fused:
+        nat.clip_reduce_noise(view, clip.cuda(), summed_in.cuda(), noise.cuda(), 0, 0, 0.0, 1.0 / ebs, summed, grad, B,
+                              ws)
+    else:
+        nat.clip_reduce(view, clip.cuda(), summed_in.cuda(), summed, B, ws)
+        nat.noise_scale(summed, noise.cuda(), 0, 0, 0.0, 1.0 / ebs, grad, P)
+    scale = np.abs(GS.numpy()).max() * np.sqrt(B)
+    assert np.abs(summed.cpu().double().numpy() - ref_sum.numpy()).max() / max(np.abs(ref_sum.numpy()).max(), 1e-30) < TOL
+    assert rel_err(grad.cpu().numpy(), ref_grad.numpy()) < TOL
+
+
+def test_clip_reduce_in_place_accumulate_matches_two_chunks(nat):
+    """BatchMemoryManager protocol: summed_grad accumulated over physical chunks == one pass."""
+    g = torch.Generator().manual_seed(3)
+    B, P = 96, 20000
+    GS = torch.randn(B, P, generator=g).cuda()
+    clip = torch.rand(B, generator=g).cuda()
+    ws = torch.empty(max(nat.clip_reduce_workspace(B, P) // 4, 4), device="cuda")
+    one = torch.zeros(P, device="cuda")
+    nat.clip_reduce(nat.FlatView(GS, 0, P), clip, None, one, B, ws)
+    two = torch.zeros(P, device="cuda")
+    h = 40
+    nat.clip_reduce(nat.FlatView(GS[:h].contiguous(), 0, P), clip[:h].contiguous(), None, two, h, ws)
+    nat.clip_reduce(nat.FlatView(GS[h:].contiguous(), 0, P), clip[h:].contiguous(), two, two, B - h, ws)
+    assert rel_err(two.cpu().numpy(), one.cpu().numpy()) < TOL
+
+
+def test_philox_stream_matches_oracle(nat):
+    from oracle import opacus_ref as O
+    n = 100003
+    out = torch.zeros(n, device="cuda")
+    nat.philox_normal(out, seed=0x1234567890ABCDEF, offset=77, std=1.5)
+    ref = O.philox_normal(n, 0x1234567890ABCDEF, 77, 1.5)
+    got = out.cpu().numpy()
+    # integer pipeline is bit-exact; float transform (log/sincos) may differ by a few ulp
+    assert np.abs(got - ref).max() < 2e-5
+    assert abs(got.mean()) < 0.02 and abs(got.std() - 1.5) < 0.02
+
+
+def test_noise_is_identical_for_same_seed_and_offset(nat):
+    a = torch.zeros(4096, device="cuda")
+    b = torch.zeros(4096, device="cuda")
+    nat.philox_normal(a, 9, 5, 1.0)
+    nat.philox_normal(b, 9, 5, 1.0)
+    assert torch.equal(a, b)
+    nat.philox_normal(b, 9, 6, 1.0)
+    assert torch.equal(a[4:], b[:-4])
+
+
+def test_argument_errors_launch_nothing(nat):
+    base = torch.zeros(2, 64, device="cuda")
+    part = torch.zeros(2, 1, device="cuda")
+    A = torch.zeros(2, 3, 4, device="cuda")
+    G = torch.zeros(2, 3, 5, device="cuda")
+    with pytest.raises(nat.DpkError):
+        nat.linear_grad_sample(A, G, nat.FlatView(base, 0, 19), None, part, 0, 1.0)  # wrong window
+    with pytest.raises(nat.DpkError):
+        nat.linear_grad_sample(A.cpu(), G, nat.FlatView(base, 0, 20), None, part, 0, 1.0)  # CPU tensor
+    with pytest.raises(nat.DpkError):
+        nat.linear_grad_sample(A, G, nat.FlatView(base, 0, 20), None, part, 1, 1.0)  # slot overflow
