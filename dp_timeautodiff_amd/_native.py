@@ -130,6 +130,8 @@ def linear_grad_sample(A, G, gs_w: FlatView, gs_b: Optional[FlatView], part: tor
     if G.shape[0] != B or G.shape[1] != T:
         raise DpkError(f"A {tuple(A.shape)} and G {tuple(G.shape)} disagree on [B,T]")
     out_f = G.shape[2]
+    if B == 0:
+        return
     if gs_w.numel != in_f * out_f or (gs_b is not None and gs_b.numel != out_f):
         raise DpkError("grad-sample window does not match the layer shape")
     if gs_w.base.shape[0] < B or part.shape[0] < B or part.dim() != 2 or part.stride(1) != 1:
@@ -148,6 +150,8 @@ def embedding_grad_sample(idx, G, gs: FlatView, V: int, part: torch.Tensor, slot
         raise DpkError("idx must be contiguous [B,T] and G contiguous [B,T,E]")
     B, T = idx.shape
     E = G.shape[2]
+    if B == 0:
+        return
     if G.shape[0] != B or G.shape[1] != T or gs.numel != V * E:
         raise DpkError("embedding grad-sample shapes disagree")
     if gs.base.shape[0] < B or part.shape[0] < B:
@@ -163,6 +167,8 @@ def layernorm_grad_sample(X, G, gs_w: FlatView, gs_b: FlatView, part: torch.Tens
     if X.dim() != 3 or X.shape != G.shape or not X.is_contiguous() or not G.is_contiguous():
         raise DpkError("X and G must be contiguous [B,T,C] of equal shape")
     B, T, C = X.shape
+    if B == 0:
+        return
     if gs_w.numel != C or gs_b.numel != C or gs_w.base.shape[0] < B or part.shape[0] < B:
         raise DpkError("layernorm grad-sample shapes disagree")
     rc = load().dpk_layernorm_grad_sample(_ptr(X), _ptr(G), gs_w.ptr, gs_b.ptr, _ptr(part), part.stride(0), slot0,

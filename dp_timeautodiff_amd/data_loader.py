@@ -1,0 +1,178 @@
+"""DPDataLoader (Poisson sampling) and its samplers.
+
+Behavioural restatement of Opacus' `opacus.data_loader.DPDataLoader` and
+`opacus.utils.uniform_sampler`: the object
+`PrivacyEngine.make_private_with_epsilon` hands back in place of the reference's shuffled
+DataLoader (Model_Code/timeautoencoder.py:664-682).  Host-side only.
+"""
+from __future__ import annotations
+
+import logging
+from functools import partial
+from typing import Any, List, Optional, Sequence, Tuple, Type, Union
+
+import torch
+from torch.utils.data import BatchSampler, DataLoader, Dataset, IterableDataset, Sampler
+from torch.utils.data._utils.collate import default_collate
+from torch.utils.data.dataloader import _collate_fn_t
+
+logger = logging.getLogger(__name__)
+
+
+class UniformWithReplacementSampler(Sampler[List[int]]):
+    """Each sample is included in a batch independently with probability `sample_rate`."""
+
+    def __init__(self, *, num_samples: int, sample_rate: float, generator=None, steps=None):
+        self.num_samples = num_samples
+        self.sample_rate = sample_rate
+        self.generator = generator
+        if self.num_samples <= 0:
+            raise ValueError("num_samples should be a positive integer value, but got num_samples={}".format(
+                self.num_samples))
+        if steps is not None:
+            self.steps = steps
+        else:
+            self.steps = int(1 / self.sample_rate)
+
+    def __len__(self):
+        return self.steps
+
+    def __iter__(self):
+        num_batches = self.steps
+        while num_batches > 0:
+            mask = torch.rand(self.num_samples, generator=self.generator) < self.sample_rate
+            indices = mask.nonzero(as_tuple=False).reshape(-1).tolist()
+            yield indices
+            num_batches -= 1
+
+
+class DistributedUniformWithReplacementSampler(Sampler[List[int]]):
+    """Poisson sampling over this rank's share of a per-epoch seeded permutation (A.7)."""
+
+    def __init__(self, *, total_size: int, sample_rate: float, shuffle: bool = True, shuffle_seed: int = 0,
+                 steps: Optional[int] = None, generator=None):
+        self.total_size = total_size
+        self.sample_rate = sample_rate
+        self.generator = generator
+        self.num_replicas = torch.distributed.get_world_size()
+        self.rank = torch.distributed.get_rank()
+        self.epoch = 0
+        self.shuffle = shuffle
+        self.shuffle_seed = shuffle_seed
+        if self.total_size <= 0:
+            raise ValueError("total_size should be a positive integer value, but got total_size={}".format(
+                self.total_size))
+        self.num_samples = self.total_size // self.num_replicas
+        if self.rank < self.total_size % self.num_replicas:
+            self.num_samples += 1
+        if steps is not None:
+            self.num_batches = steps
+        else:
+            self.num_batches = int(1 / self.sample_rate)
+
+    def __len__(self):
+        return self.num_batches
+
+    def __iter__(self):
+        if self.shuffle:
+            g = torch.Generator()
+            g.manual_seed(self.shuffle_seed + self.epoch)
+            indices = torch.randperm(self.total_size, generator=g)
+        else:
+            indices = torch.arange(self.total_size)
+        indices = indices[self.rank:self.total_size:self.num_replicas]
+        assert len(indices) == self.num_samples
+        for _ in range(self.num_batches):
+            mask = torch.rand(self.num_samples, generator=self.generator) < self.sample_rate
+            selected_examples = mask.nonzero(as_tuple=False).reshape(-1)
+            if len(selected_examples) > 0:
+                yield indices[selected_examples].tolist()
+            else:
+                yield []
+
+    def set_epoch(self, epoch: int):
+        self.epoch = epoch
+
+
+def shape_safe(x: Any) -> Tuple:
+    return getattr(x, "shape", ())
+
+
+def dtype_safe(x: Any) -> Union[torch.dtype, Type]:
+    return getattr(x, "dtype", type(x))
+
+
+def collate(batch: List[torch.Tensor], *, collate_fn: Optional[_collate_fn_t], sample_empty_shapes: Sequence[Tuple],
+            dtypes: Sequence[Union[torch.dtype, Type]]):
+    """Collate that tolerates the empty batches Poisson sampling produces (zero-length tensors)."""
+    if len(batch) > 0:
+        return collate_fn(batch)
+    return [torch.zeros(shape, dtype=dtype) for shape, dtype in zip(sample_empty_shapes, dtypes)]
+
+
+def wrap_collate_with_empty(*, collate_fn: Optional[_collate_fn_t], sample_empty_shapes, dtypes):
+    return partial(collate, collate_fn=collate_fn, sample_empty_shapes=sample_empty_shapes, dtypes=dtypes)
+
+
+class DPDataLoader(DataLoader):
+    """DataLoader whose batches are Poisson samples with rate `sample_rate` (logical batch size is random)."""
+
+    def __init__(self, dataset: Dataset, *, sample_rate: float, collate_fn: Optional[_collate_fn_t] = None,
+                 drop_last: bool = False, generator=None, distributed: bool = False, **kwargs):
+        self.sample_rate = sample_rate
+        self.distributed = distributed
+        if distributed:
+            batch_sampler = DistributedUniformWithReplacementSampler(
+                total_size=len(dataset), sample_rate=sample_rate, generator=generator)
+        else:
+            batch_sampler = UniformWithReplacementSampler(
+                num_samples=len(dataset), sample_rate=sample_rate, generator=generator)
+        sample_empty_shapes = [(0, *shape_safe(x)) for x in dataset[0]]
+        dtypes = [dtype_safe(x) for x in dataset[0]]
+        if collate_fn is None:
+            collate_fn = default_collate
+        if drop_last:
+            logger.warning("Ignoring drop_last as it is not compatible with DPDataLoader.")
+        super().__init__(
+            dataset=dataset, batch_sampler=batch_sampler,
+            collate_fn=wrap_collate_with_empty(collate_fn=collate_fn, sample_empty_shapes=sample_empty_shapes,
+                                               dtypes=dtypes),
+            generator=generator, **kwargs)
+
+    @classmethod
+    def from_data_loader(cls, data_loader: DataLoader, *, distributed: bool = False, generator=None):
+        if isinstance(data_loader.dataset, IterableDataset):
+            raise ValueError("Uniform sampling is not supported for IterableDataset")
+        return cls(
+            dataset=data_loader.dataset, sample_rate=1 / len(data_loader), num_workers=data_loader.num_workers,
+            collate_fn=data_loader.collate_fn, pin_memory=data_loader.pin_memory, drop_last=data_loader.drop_last,
+            timeout=data_loader.timeout, worker_init_fn=data_loader.worker_init_fn,
+            multiprocessing_context=data_loader.multiprocessing_context,
+            generator=generator if generator else data_loader.generator,
+            prefetch_factor=data_loader.prefetch_factor, persistent_workers=data_loader.persistent_workers,
+            distributed=distributed)
+
+
+def _is_supported_batch_sampler(sampler: Sampler):
+    return isinstance(sampler, (BatchSampler, UniformWithReplacementSampler,
+                                DistributedUniformWithReplacementSampler))
+
+
+def switch_generator(*, data_loader: DataLoader, generator):
+    """Re-create `data_loader` with a different random generator (secure_mode / noise_generator plumbing)."""
+    batch_sampler = data_loader.batch_sampler
+    if batch_sampler is None or not _is_supported_batch_sampler(batch_sampler):
+        raise ValueError("Non-batch processing is not supported: Opacus always assumes one of the input dimensions "
+                         "to be batch dimension.")
+    if isinstance(batch_sampler, BatchSampler):
+        if not hasattr(batch_sampler.sampler, "generator"):
+            raise ValueError("Target sampler doesn't have generator attribute: nothing to switch")
+        batch_sampler.sampler.generator = generator
+    else:
+        batch_sampler.generator = generator
+    return DataLoader(
+        dataset=data_loader.dataset, batch_sampler=batch_sampler, num_workers=data_loader.num_workers,
+        collate_fn=data_loader.collate_fn, pin_memory=data_loader.pin_memory, drop_last=data_loader.drop_last,
+        timeout=data_loader.timeout, worker_init_fn=data_loader.worker_init_fn,
+        multiprocessing_context=data_loader.multiprocessing_context, generator=generator,
+        prefetch_factor=data_loader.prefetch_factor, persistent_workers=data_loader.persistent_workers)

@@ -1,0 +1,401 @@
+"""GradSampleModule (hooks mode) on top of the HIP per-sample-gradient kernels.
+
+Drop-in for the object `PrivacyEngine.make_private_with_epsilon` returns as `ae` at
+Model_Code/timeautoencoder.py:674 (Opacus' `GradSampleModule`):
+
+  * forward hooks stash the (detached) input of every call of every Linear / Embedding / LayerNorm
+    (fired by `ae(batch_input)`, :734) and bump the parameters' `_forward_counter`;
+  * backward hooks (fired by `loss_Auto.backward()`, :749) pair each stashed input with its
+    grad_output; when a layer's counter returns to 0 its per-sample gradient is materialised.
+
+MI355X-first differences (observable state after backward is the same: `p.grad_sample` of shape
+[B, *p.shape], fp32, on the parameter's device):
+
+  * a layer invoked T times per forward (the CustomGRU gates, timeautoencoder.py:84-94; DPLSTM cells)
+    is NOT contracted T times into a [B, out, in] buffer.  Its T (input, grad_output) pairs are stacked
+    and contracted by ONE K=T MFMA GEMM launch (dpk_linear_grad_sample);
+  * all per-sample gradients live in one persistent flat arena [B_capacity, P] (one allocation, reused
+    every step; `p.grad_sample` is a strided view into it), so the optimizer's clip/sum/noise pass is a
+    single launch over the whole parameter vector;
+  * every kernel also emits the squared norm of what it wrote, so the norm pass never re-reads HBM.
+"""
+from __future__ import annotations
+
+from typing import Dict, Iterable, List, Optional, Tuple
+
+import torch
+import torch.nn as nn
+
+from . import _native
+from .layers import RNNLinear
+
+ARENA_ALIGN = 64  # floats: every parameter window starts on a 256-byte boundary
+
+
+class _ParamWindow:
+    __slots__ = ("name", "param", "offset", "numel")
+
+    def __init__(self, name, param, offset):
+        self.name, self.param, self.offset, self.numel = name, param, offset, param.numel()
+
+
+class GradSampleArena:
+    """Flat device storage of one step's per-sample gradients + the DP tail's small buffers.
+
+    buf     [capacity, P]   per-sample gradients (row = sample); P padded so rows are 256-B aligned
+    part    [capacity, S]   squared-norm partials, S = sum of every layer's slots
+    clip / norms [capacity]
+    summed, grad [P]        clipped sum (p.summed_grad views) and final gradient (p.grad views)
+    """
+
+    def __init__(self, named_params: Iterable[Tuple[str, nn.Parameter]], device: torch.device):
+        self.device = device
+        self.windows: Dict[int, _ParamWindow] = {}
+        off = 0
+        for name, p in named_params:
+            if not p.requires_grad or id(p) in self.windows:
+                continue
+            if p.dtype != torch.float32:
+                raise ValueError(f"{name}: only fp32 parameters are supported (got {p.dtype})")
+            self.windows[id(p)] = _ParamWindow(name, p, off)
+            off += (p.numel() + ARENA_ALIGN - 1) // ARENA_ALIGN * ARENA_ALIGN
+        self.P = max(off, ARENA_ALIGN)
+        self.n_slots = 0
+        self.capacity = 0
+        self.buf = None
+        self.part = None
+        self.clip = None
+        self.norms = None
+        self.summed = torch.zeros(self.P, device=device, dtype=torch.float32)
+        self.grad = torch.zeros(self.P, device=device, dtype=torch.float32)
+        self.workspace = None
+        self.summed_valid = False
+        self.pass_B: List[int] = []  # batch size of every un-stepped backward pass
+        self.consumed = False
+
+    # -- allocation -----------------------------------------------------------------------------------
+    def reserve_slots(self, n: int) -> int:
+        s0 = self.n_slots
+        self.n_slots += n
+        return s0
+
+    def ensure(self, rows: int):
+        if rows <= self.capacity:
+            return
+        new_cap = max(rows, int(self.capacity * 1.25) + 8)
+        new_cap = (new_cap + 7) // 8 * 8
+        old = self.buf
+        live = sum(self.pass_B[:-1]) if len(self.pass_B) > 1 else 0
+        S = max((self.n_slots + 3) // 4 * 4, 4)
+        buf = torch.zeros(new_cap, self.P, device=self.device, dtype=torch.float32)
+        part = torch.zeros(new_cap, S, device=self.device, dtype=torch.float32)
+        if old is not None and live > 0:  # keep earlier passes of an accumulating step
+            buf[:live].copy_(old[:live])
+            part[:live].copy_(self.part[:live])
+        self.buf, self.part = buf, part
+        self.clip = torch.zeros(new_cap, device=self.device, dtype=torch.float32)
+        self.norms = torch.zeros(new_cap, device=self.device, dtype=torch.float32)
+        self.capacity = new_cap
+        del old
+
+    def ensure_workspace(self, B: int):
+        need = _native.clip_reduce_workspace(B, self.P)
+        if need and (self.workspace is None or self.workspace.numel() * 4 < need):
+            self.workspace = torch.empty((need + 3) // 4, device=self.device, dtype=torch.float32)
+        return self.workspace if need else None
+
+    # -- views ----------------------------------------------------------------------------------------
+    def window(self, p: nn.Parameter) -> _ParamWindow:
+        return self.windows[id(p)]
+
+    def flat(self, p: nn.Parameter, row0: int = 0) -> _native.FlatView:
+        w = self.windows[id(p)]
+        return _native.FlatView(self.buf[row0:] if row0 else self.buf, w.offset, w.numel)
+
+    def sample_view(self, p: nn.Parameter, row0: int, rows: int) -> torch.Tensor:
+        w = self.windows[id(p)]
+        return self.buf[row0:row0 + rows, w.offset:w.offset + w.numel].view(rows, *p.shape)
+
+    def vec_view(self, vec: torch.Tensor, p: nn.Parameter) -> torch.Tensor:
+        w = self.windows[id(p)]
+        return vec[w.offset:w.offset + w.numel].view(p.shape)
+
+    @property
+    def rows(self) -> int:
+        return sum(self.pass_B)
+
+    def reset_pass(self):
+        self.pass_B = []
+        self.consumed = False
+
+
+class _Layer:
+    """Hook state of one sampled leaf module."""
+
+    def __init__(self, name: str, module: nn.Module, kind: str, slot0: int, nslots: int):
+        self.name, self.module, self.kind, self.slot0, self.nslots = name, module, kind, slot0, nslots
+        self.acts: List[torch.Tensor] = []
+        self.pairs: List[Tuple[torch.Tensor, torch.Tensor]] = []
+        self.counter = 0
+        self.passes_written = 0
+
+
+def _kind_of(m: nn.Module) -> Optional[str]:
+    t = type(m)
+    if t in (nn.Linear, RNNLinear):
+        return "linear"
+    if t is nn.Embedding:
+        return "embedding"
+    if t is nn.LayerNorm:
+        return "layernorm"
+    return None
+
+
+class GradSampleModule(nn.Module):
+    """Wraps `m`; after backward every trainable parameter has `.grad_sample` ([B, *shape] view)."""
+
+    def __init__(self, m: nn.Module, *, batch_first: bool = True, loss_reduction: str = "mean",
+                 strict: bool = True, force_functorch: bool = False):
+        super().__init__()
+        if loss_reduction not in ("mean", "sum"):
+            raise ValueError(f"loss_reduction = {loss_reduction}. Only 'sum' and 'mean' losses are supported")
+        self._module = m
+        self.batch_first = batch_first
+        self.loss_reduction = loss_reduction
+        self.hooks_enabled = True
+        self.forbid_grad_accumulation = False  # set by PrivacyEngine when Poisson sampling is on
+        self._layers: List[_Layer] = []
+        self._handles = []
+
+        params = [(n, p) for n, p in m.named_parameters() if p.requires_grad]
+        if not params:
+            raise ValueError("module has no trainable parameters")
+        device = params[0][1].device
+        if device.type != "cuda" and not getattr(_native, "_ALLOW_NON_CUDA", False):
+            raise _native.DpkError(
+                "GradSampleModule needs the module on a HIP device (cuda:N): the per-sample-gradient path "
+                "runs only in hand-written gfx950 kernels; there is no CPU fallback")
+        errors = self.validate(m, strict=strict)
+        if errors and strict:
+            raise NotImplementedError(f"Model contains layers without a per-sample-gradient kernel: {errors}")
+        self.arena = GradSampleArena(params, device)
+
+        covered = set()
+        for name, sub in m.named_modules():
+            own = [p for p in sub.parameters(recurse=False) if p.requires_grad]
+            if not own:
+                continue
+            kind = _kind_of(sub)
+            if kind is None:
+                continue
+            if kind == "linear":
+                n = _native.linear_slots(sub.in_features, sub.out_features)
+            elif kind == "layernorm":
+                if len(sub.normalized_shape) != 1 or not sub.elementwise_affine:
+                    raise NotImplementedError(f"{name}: only affine LayerNorm over the last dim is supported")
+                n = 1
+            else:
+                if sub.padding_idx is not None:
+                    raise NotImplementedError(f"{name}: nn.Embedding with padding_idx is not supported")
+                n = 1
+            if any(not p.requires_grad for p in sub.parameters(recurse=False)):
+                raise NotImplementedError(f"{name}: partially frozen layers are not supported")
+            layer = _Layer(name, sub, kind, self.arena.reserve_slots(n), n)
+            self._layers.append(layer)
+            for p in own:
+                covered.add(id(p))
+            self._handles.append(sub.register_forward_hook(self._make_fwd(layer)))
+            self._handles.append(sub.register_full_backward_hook(self._make_bwd(layer)))
+        for n_, p in params:
+            p.grad_sample = None
+            p._forward_counter = 0
+            p._dpk_arena = self.arena
+            if id(p) not in covered and strict:
+                raise NotImplementedError(f"parameter {n_} is owned by a module without a per-sample-gradient kernel")
+
+    # ---- nn.Module plumbing -------------------------------------------------------------------------
+    def forward(self, *args, **kwargs):
+        return self._module(*args, **kwargs)
+
+    def __getattr__(self, item):
+        try:
+            return super().__getattr__(item)
+        except AttributeError as e:
+            submodules = dict(self._module.named_modules())
+            if item and item in submodules:
+                return submodules[item]
+            if "_module" in self.__dict__.get("_modules", {}):
+                return getattr(self._modules["_module"], item)
+            raise e
+
+    def state_dict(self, *args, **kwargs):
+        return self._module.state_dict(*args, **kwargs)
+
+    def load_state_dict(self, state_dict, strict: bool = True, **kwargs):
+        return self._module.load_state_dict(state_dict, strict=strict, **kwargs)
+
+    def zero_grad(self, set_to_none: bool = False):
+        if set_to_none is False:
+            pass  # grad_sample is always dropped, as upstream
+        for p in self.parameters():
+            p.grad_sample = None
+        self._reset_step_state()
+        super().zero_grad(set_to_none)
+
+    def _reset_step_state(self):
+        self.arena.reset_pass()
+        for layer in self._layers:
+            layer.passes_written = 0
+
+    def del_grad_sample(self):
+        for p in self.parameters():
+            p.grad_sample = None
+        self._reset_step_state()
+
+    def to_standard_module(self) -> nn.Module:
+        self._close()
+        return self._module
+
+    def remove_hooks(self):
+        for h in self._handles:
+            h.remove()
+        self._handles = []
+
+    def disable_hooks(self):
+        self.hooks_enabled = False
+
+    def enable_hooks(self):
+        self.hooks_enabled = True
+
+    def _close(self):
+        self.remove_hooks()
+        for p in self._module.parameters():
+            for attr in ("grad_sample", "_forward_counter", "_dpk_arena", "summed_grad"):
+                if hasattr(p, attr):
+                    delattr(p, attr)
+
+    def __repr__(self):
+        return f"GradSampleModule({self._module.__repr__()})"
+
+    @classmethod
+    def validate(cls, module: nn.Module, *, strict: bool = False) -> List[NotImplementedError]:
+        errors = []
+        for name, sub in module.named_modules():
+            own = [p for p in sub.parameters(recurse=False) if p.requires_grad]
+            if own and _kind_of(sub) is None:
+                errors.append(NotImplementedError(
+                    f"{name or 'Main'} ({type(sub).__name__}) owns trainable parameters but has no "
+                    "per-sample-gradient kernel"))
+        if strict and errors:
+            raise NotImplementedError(errors)
+        return errors
+
+    # ---- hooks ----------------------------------------------------------------------------------------
+    def _make_fwd(self, layer: _Layer):
+        def hook(module, inputs, output):
+            if not self.hooks_enabled or not module.training or not torch.is_grad_enabled():
+                return
+            layer.acts.append(inputs[0].detach())
+            layer.counter += 1
+            for p in module.parameters(recurse=False):
+                if p.requires_grad:
+                    p._forward_counter += 1
+
+        return hook
+
+    def _make_bwd(self, layer: _Layer):
+        def hook(module, grad_input, grad_output):
+            if not self.hooks_enabled or not layer.acts:
+                return
+            g = grad_output[0]
+            if g is None:
+                raise RuntimeError(f"{layer.name}: no gradient reached this layer's output")
+            a = layer.acts.pop()  # LIFO: backward visits calls in reverse
+            layer.pairs.append((a, g.detach()))
+            layer.counter -= 1
+            for p in module.parameters(recurse=False):
+                if p.requires_grad:
+                    p._forward_counter -= 1
+            if layer.counter == 0:
+                self._materialise(layer)
+
+        return hook
+
+    # ---- the deferred contraction ---------------------------------------------------------------------
+    def _stack(self, tensors: List[torch.Tensor], feat_dims: int) -> torch.Tensor:
+        """calls x [B, *, F]  ->  contiguous [B, T_total, F] (feat_dims=1) or [B, T_total] (indices)."""
+        flat = []
+        for t in tensors:
+            if not self.batch_first and t.dim() >= 2 + feat_dims:
+                t = t.transpose(0, 1)
+            if feat_dims == 0:
+                flat.append(t.reshape(t.shape[0], -1))
+            elif t.dim() == 2:
+                flat.append(t.unsqueeze(1))
+            else:
+                flat.append(t.reshape(t.shape[0], -1, t.shape[-1]))
+        if len(flat) == 1:
+            return flat[0].contiguous()
+        B = flat[0].shape[0]
+        if any(f.shape[0] != B for f in flat):
+            raise NotImplementedError("a layer was called with different batch sizes within one forward pass")
+        return torch.cat(flat, dim=1)
+
+    def _materialise(self, layer: _Layer):
+        arena = self.arena
+        pairs = layer.pairs[::-1]  # back to forward order (t ascending)
+        layer.pairs = []
+        m = layer.module
+        if layer.kind == "embedding":
+            A = self._stack([p[0] for p in pairs], 0).to(torch.int64)
+        else:
+            A = self._stack([p[0] for p in pairs], 1)
+        G = self._stack([p[1] for p in pairs], 1)
+        if G.dtype != torch.float32 or (layer.kind != "embedding" and A.dtype != torch.float32):
+            raise _native.DpkError(f"{layer.name}: only fp32 activations/backprops are supported")
+        B = A.shape[0]
+        k = layer.passes_written  # index of the un-stepped backward pass this belongs to
+        if k >= 1 and self.forbid_grad_accumulation:
+            raise ValueError("Poisson sampling is not compatible with grad accumulation. You need to call "
+                             "optimizer.step() after every forward/backward pass or consider using "
+                             "BatchMemoryManager")
+        if k == len(arena.pass_B):
+            arena.pass_B.append(B)
+        elif k < len(arena.pass_B):
+            if arena.pass_B[k] != B:
+                raise ValueError(f"{layer.name}: batch size {B} differs from {arena.pass_B[k]} seen by other layers")
+        else:
+            raise RuntimeError("per-sample-gradient bookkeeping out of sync (missing zero_grad?)")
+        row0 = sum(arena.pass_B[:k])
+        arena.ensure(max(row0 + B, 1))
+        layer.passes_written += 1
+        g_scale = float(B) if self.loss_reduction == "mean" else 1.0
+        part = arena.part[row0:] if row0 else arena.part
+        if B > 0:
+            if layer.kind == "linear":
+                vb = arena.flat(m.bias, row0) if m.bias is not None else None
+                _native.linear_grad_sample(A, G, arena.flat(m.weight, row0), vb, part, layer.slot0, g_scale)
+            elif layer.kind == "embedding":
+                _native.embedding_grad_sample(A, G, arena.flat(m.weight, row0), m.num_embeddings, part,
+                                              layer.slot0, g_scale)
+            else:
+                _native.layernorm_grad_sample(A, G, arena.flat(m.weight, row0), arena.flat(m.bias, row0), part,
+                                              layer.slot0, m.eps, g_scale)
+        for p in m.parameters(recurse=False):
+            v = arena.sample_view(p, row0, B)
+            if k == 0:
+                p.grad_sample = v
+            elif isinstance(p.grad_sample, list):
+                p.grad_sample.append(v)
+            else:
+                p.grad_sample = [p.grad_sample, v]
+
+    # ---- used by the optimizer ------------------------------------------------------------------------
+    def check_complete(self):
+        n = len(self.arena.pass_B)
+        for layer in self._layers:
+            if layer.passes_written != n:
+                raise ValueError(
+                    f"Per sample gradient is not initialized for layer '{layer.name}' "
+                    f"({layer.passes_written} of {n} backward passes reached it). "
+                    "Not updated in backward pass?")

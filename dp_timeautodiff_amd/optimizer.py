@@ -1,0 +1,319 @@
+"""DPOptimizer / DistributedDPOptimizer on the fused HIP tail (K6 + K7).
+
+Drop-in for the optimizer `PrivacyEngine.make_private_with_epsilon` returns at
+Model_Code/timeautoencoder.py:674 and the reference drives with `optimizer_ae.zero_grad()` (:732) and
+`optimizer_ae.step()` (:751).  Behaviour follows Opacus' `DPOptimizer`:
+
+    step() -> pre_step():
+        clip_and_accumulate   per-sample norm over ALL parameter groups, clip factor
+                              min(1, C/(norm+1e-6)), clipped weighted sum into p.summed_grad
+        [skip flag set -> return]      (BatchMemoryManager: non-final physical chunk)
+        add_noise             p.grad = p.summed_grad + N(0, (sigma*C)^2)
+        scale_grad            p.grad /= expected_batch_size * accumulated_iterations
+        step_hook             accountant.step(...)
+    -> original_optimizer.step()
+
+MI355X-first: the per-sample norms were already emitted by the grad-sample kernels, so
+clip_and_accumulate is one tiny launch (K6) plus ONE streaming launch over the whole flat arena that
+reads every per-sample gradient exactly once (K7); on a real (non-skipped) step noise and scale are fused
+into that same launch.  Noise comes from a counter-based Philox4x32-10 stream keyed by (seed, step), so
+every rank of a data-parallel job draws the identical tensor with no communication.
+"""
+from __future__ import annotations
+
+import os
+from collections import deque
+from typing import Callable, List, Optional
+
+import torch
+from torch.optim import Optimizer
+
+from . import _native
+
+
+def _generate_seed() -> int:
+    return int.from_bytes(os.urandom(8), "little")
+
+
+class DPOptimizer(Optimizer):
+    def __init__(self, optimizer: Optimizer, *, noise_multiplier: float, max_grad_norm: float,
+                 expected_batch_size: Optional[int], loss_reduction: str = "mean", generator=None,
+                 secure_mode: bool = False, noise_seed: Optional[int] = None, **kwargs):
+        if loss_reduction not in ("mean", "sum"):
+            raise ValueError(f"Unexpected value for loss_reduction: {loss_reduction}")
+        if loss_reduction == "mean" and expected_batch_size is None:
+            raise ValueError("You must provide expected batch size of the loss reduction is mean")
+        self.original_optimizer = optimizer
+        self.noise_multiplier = noise_multiplier
+        self.max_grad_norm = max_grad_norm
+        self.loss_reduction = loss_reduction
+        self.expected_batch_size = expected_batch_size
+        self.step_hook: Optional[Callable[["DPOptimizer"], None]] = None
+        self.generator = generator
+        self.secure_mode = secure_mode
+        self.param_groups = self.original_optimizer.param_groups
+        self.defaults = self.original_optimizer.defaults
+        self.state = self.original_optimizer.state
+        self._step_skip_queue = deque()
+        self._is_last_step_skipped = False
+        self.noise_seed = _generate_seed() if noise_seed is None else int(noise_seed)
+        self._noise_offset = 0  # Philox blocks consumed so far (advances by P/4 per real step)
+        self._injected_noise: Optional[torch.Tensor] = None
+        self._arena = None
+        self._gsm = None
+        for p in self.params:
+            p.summed_grad = None
+
+    # ---- wiring -------------------------------------------------------------------------------------
+    @property
+    def params(self) -> List[torch.nn.Parameter]:
+        return [p for group in self.param_groups for p in group["params"] if p.requires_grad]
+
+    def attach_grad_sample_module(self, gsm):
+        """Bind to the GradSampleModule whose arena holds this optimizer's per-sample gradients."""
+        self._gsm = gsm
+        self._arena = gsm.arena
+        missing = [i for i, p in enumerate(self.params) if id(p) not in self._arena.windows]
+        if missing:
+            raise ValueError("optimizer holds trainable parameters that are not in the GradSampleModule")
+
+    @property
+    def arena(self):
+        if self._arena is None:
+            ps = self.params
+            a = getattr(ps[0], "_dpk_arena", None) if ps else None
+            if a is None:
+                raise ValueError("DPOptimizer is not attached to a GradSampleModule (parameters carry no "
+                                 "per-sample-gradient arena); wrap the module with GradSampleModule first")
+            if any(getattr(p, "_dpk_arena", None) is not a for p in ps):
+                raise ValueError("all parameters of a DPOptimizer must belong to one GradSampleModule")
+            self._arena = a
+        return self._arena
+
+    # ---- Opacus-visible properties ------------------------------------------------------------------
+    @property
+    def grad_samples(self) -> List[torch.Tensor]:
+        ret = []
+        for p in self.params:
+            gs = getattr(p, "grad_sample", None)
+            if gs is None:
+                raise ValueError("Per sample gradient not found. Are you using GradSampleModule?")
+            ret.append(torch.cat(gs, dim=0) if isinstance(gs, list) else gs)
+        return ret
+
+    @property
+    def accumulated_iterations(self) -> int:
+        n = len(self.arena.pass_B)
+        return max(n, 1)
+
+    def signal_skip_step(self, do_skip=True):
+        self._step_skip_queue.append(do_skip)
+
+    def _check_skip_next_step(self, pop_next=True):
+        if self._step_skip_queue:
+            if pop_next:
+                return self._step_skip_queue.popleft()
+            return self._step_skip_queue[0]
+        return False
+
+    def attach_step_hook(self, fn: Callable[["DPOptimizer"], None]):
+        self.step_hook = fn
+
+    def inject_noise(self, flat_noise: torch.Tensor):
+        """Parity/testing: use this [P_arena] tensor (already scaled by sigma*C) for the next real step."""
+        self._injected_noise = flat_noise
+
+    # ---- the DP tail --------------------------------------------------------------------------------
+    def _prepare(self):
+        arena = self.arena
+        for p in self.params:
+            if getattr(p, "grad_sample", None) is None:
+                raise ValueError("Per sample gradient is not initialized. Not updated in backward pass?")
+        if self._gsm is not None:
+            self._gsm.check_complete()
+        if arena.consumed:
+            raise ValueError("Per-sample gradients were already processed by a previous step(); call "
+                             "zero_grad() before the next backward pass")
+        return arena, arena.rows
+
+    def _clip_factors(self, arena, B):
+        if B > 0:
+            _native.clip_factors(arena.part, arena.n_slots, arena.clip, arena.norms, B, self.max_grad_norm)
+
+    def clip_and_accumulate(self):
+        """K6 + K7a: p.summed_grad (+)= sum_b clip_b * grad_sample_b  — one pass over the arena."""
+        arena, B = self._prepare()
+        arena.ensure(max(B, 1))
+        self._clip_factors(arena, B)
+        ws = arena.ensure_workspace(B)
+        _native.clip_reduce(_native.FlatView(arena.buf, 0, arena.P), arena.clip,
+                            arena.summed if arena.summed_valid else None, arena.summed, B, ws)
+        arena.summed_valid = True
+        arena.consumed = True
+        self._publish_summed(arena)
+
+    def _publish_summed(self, arena):
+        for p in self.params:
+            p.summed_grad = arena.vec_view(arena.summed, p)
+
+    def _publish_grad(self, arena):
+        for p in self.params:
+            p.grad = arena.vec_view(arena.grad, p)
+
+    def _noise_args(self, arena):
+        std = float(self.noise_multiplier) * float(self.max_grad_norm)
+        if self._injected_noise is not None:
+            z = self._injected_noise
+            self._injected_noise = None
+            if z.numel() != arena.P or z.device != arena.summed.device:
+                raise ValueError(f"injected noise must be a device tensor of {arena.P} floats (arena layout)")
+            return z, 0, 0, 0.0
+        if std == 0:
+            return None, 0, 0, 0.0
+        if self.generator is not None:  # Opacus' `noise_generator=` argument
+            z = torch.normal(mean=0.0, std=std, size=(arena.P,), device=arena.device, generator=self.generator)
+            return z, 0, 0, 0.0
+        off = self._noise_offset
+        self._noise_offset += arena.P // 4
+        return None, self.noise_seed, off, std
+
+    def add_noise(self):
+        """K7b with unit scale: p.grad = p.summed_grad + N(0, (sigma*C)^2)."""
+        arena = self.arena
+        noise, seed, off, std = self._noise_args(arena)
+        _native.noise_scale(arena.summed, noise, seed, off, std, 1.0, arena.grad, arena.P)
+        self._publish_grad(arena)
+
+    def scale_grad(self):
+        if self.loss_reduction == "mean":
+            self.arena.grad.div_(self.expected_batch_size * self.accumulated_iterations)
+
+    def _inv_scale(self) -> float:
+        if self.loss_reduction == "mean":
+            return 1.0 / (self.expected_batch_size * self.accumulated_iterations)
+        return 1.0
+
+    def _reduce_noise_scale(self, arena, B):
+        """Real step: K7 fused (clipped sum + noise + scale in the same pass over the arena)."""
+        noise, seed, off, std = self._noise_args(arena)
+        ws = arena.ensure_workspace(B)
+        _native.clip_reduce_noise(_native.FlatView(arena.buf, 0, arena.P), arena.clip,
+                                  arena.summed if arena.summed_valid else None, noise, seed, off, std,
+                                  self._inv_scale(), arena.summed, arena.grad, B, ws)
+        arena.summed_valid = True
+
+    def pre_step(self, closure: Optional[Callable[[], float]] = None) -> Optional[float]:
+        ps = self.params
+        if not ps or all(getattr(p, "grad_sample", None) is None for p in ps) and not self.arena.pass_B:
+            # no backward pass since the last zero_grad: nothing to clip (upstream returns True here)
+            return True
+        arena, B = self._prepare()
+        arena.ensure(max(B, 1))
+        if self._check_skip_next_step():
+            self._clip_factors(arena, B)
+            ws = arena.ensure_workspace(B)
+            _native.clip_reduce(_native.FlatView(arena.buf, 0, arena.P), arena.clip,
+                                arena.summed if arena.summed_valid else None, arena.summed, B, ws)
+            arena.summed_valid = True
+            arena.consumed = True
+            self._publish_summed(arena)
+            self._is_last_step_skipped = True
+            return False
+        self._clip_factors(arena, B)
+        self._reduce_noise_scale(arena, B)
+        arena.consumed = True
+        self._publish_summed(arena)
+        self._publish_grad(arena)
+        if self.step_hook:
+            self.step_hook(self)
+        self._is_last_step_skipped = False
+        return True
+
+    def step(self, closure: Optional[Callable[[], float]] = None) -> Optional[float]:
+        if closure is not None:
+            with torch.enable_grad():
+                closure()
+        if self.pre_step():
+            return self.original_optimizer.step()
+        return None
+
+    def zero_grad(self, set_to_none: bool = False):
+        for p in self.params:
+            p.grad_sample = None
+            if not self._is_last_step_skipped:
+                p.summed_grad = None
+        arena = self._arena if self._arena is not None else getattr(self.params[0], "_dpk_arena", None)
+        if arena is not None:
+            if not self._is_last_step_skipped:
+                arena.summed_valid = False
+            arena.reset_pass()
+        if self._gsm is not None:
+            for layer in self._gsm._layers:
+                layer.passes_written = 0
+        self.original_optimizer.zero_grad(set_to_none)
+
+    # ---- last-step diagnostics (device tensors, valid after step()) ------------------------------------
+    @property
+    def per_sample_norms(self) -> torch.Tensor:
+        return self.arena.norms[: self.arena.rows]
+
+    @property
+    def per_sample_clip_factor(self) -> torch.Tensor:
+        return self.arena.clip[: self.arena.rows]
+
+    # ---- torch.optim.Optimizer plumbing ---------------------------------------------------------------
+    def __repr__(self):
+        return self.original_optimizer.__repr__()
+
+    def state_dict(self):
+        return self.original_optimizer.state_dict()
+
+    def load_state_dict(self, state_dict) -> None:
+        self.original_optimizer.load_state_dict(state_dict)
+
+
+class DistributedDPOptimizer(DPOptimizer):
+    """Data-parallel DP-SGD: each rank clips ITS examples locally; the flat clipped sums are all-reduced
+    once (RCCL over xGMI when the process group is nccl); identical Philox noise is then added on every
+    rank and the result divided by the *global* expected batch size.
+
+    Equivalent to Opacus' DistributedDPOptimizer (rank-0 noise, per-parameter all_reduce, / world_size —
+    SURVEY.md Appendix A.7) but with ONE collective per step on one flat [P] buffer instead of one per
+    parameter, and no dependence on rank 0 for the noise.  `expected_batch_size` is per rank, as upstream.
+    """
+
+    def __init__(self, optimizer: Optimizer, *, noise_multiplier: float, max_grad_norm: float,
+                 expected_batch_size: Optional[int], loss_reduction: str = "mean", generator=None,
+                 secure_mode: bool = False, noise_seed: Optional[int] = None, process_group=None, **kwargs):
+        super().__init__(optimizer, noise_multiplier=noise_multiplier, max_grad_norm=max_grad_norm,
+                         expected_batch_size=expected_batch_size, loss_reduction=loss_reduction,
+                         generator=generator, secure_mode=secure_mode, noise_seed=noise_seed)
+        import torch.distributed as dist
+        self._dist = dist
+        self.process_group = process_group
+        self.rank = dist.get_rank(process_group)
+        self.world_size = dist.get_world_size(process_group)
+        # one shared noise seed: rank 0's
+        dev = self.params[0].device
+        seed_t = torch.tensor([self.noise_seed & 0x7FFFFFFFFFFFFFFF], dtype=torch.int64, device=dev)
+        dist.broadcast(seed_t, src=0, group=process_group)
+        self.noise_seed = int(seed_t.item())
+        if generator is not None:
+            raise ValueError("DistributedDPOptimizer draws noise from the shared Philox stream; "
+                             "a torch generator cannot be shared across ranks")
+
+    def _inv_scale(self) -> float:
+        s = super()._inv_scale()
+        return s / self.world_size if self.loss_reduction == "mean" else s
+
+    def _reduce_noise_scale(self, arena, B):
+        ws = arena.ensure_workspace(B)
+        _native.clip_reduce(_native.FlatView(arena.buf, 0, arena.P), arena.clip,
+                            arena.summed if arena.summed_valid else None, arena.summed, B, ws)
+        arena.summed_valid = True
+        self._dist.all_reduce(arena.summed, op=self._dist.ReduceOp.SUM, group=self.process_group)
+        noise, seed, off, std = self._noise_args(arena)
+        _native.noise_scale(arena.summed, noise, seed, off, std, self._inv_scale(), arena.grad, arena.P)
+
+    def add_noise(self):
+        raise NotImplementedError("use step(): the distributed path all-reduces between sum and noise")

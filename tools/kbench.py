@@ -1,0 +1,54 @@
+"""Micro-benchmark of the individual kernels at the BASELINE.json config shapes (GPU box)."""
+import sys, os, json, argparse
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from dp_timeautodiff_amd import _native as nat
+
+def timeit(fn, iters=20, warm=3):
+    for _ in range(warm): fn()
+    torch.cuda.synchronize()
+    e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(iters): fn()
+    e1.record(); torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / iters
+
+def bench_linear(B, T, in_f, out_f):
+    A = torch.randn(B, T, in_f, device="cuda"); G = torch.randn(B, T, out_f, device="cuda")
+    n = in_f * out_f
+    stride = (n + out_f + 63) // 64 * 64
+    base = torch.zeros(B, stride, device="cuda")
+    part = torch.zeros(B, nat.linear_slots(in_f, out_f), device="cuda")
+    vw = nat.FlatView(base, 0, n); vb = nat.FlatView(base, n, out_f)
+    ms = timeit(lambda: nat.linear_grad_sample(A, G, vw, vb, part, 0, float(B)))
+    wbytes = B * (n + out_f) * 4; rbytes = B * T * (in_f + out_f) * 4
+    flops = 2.0 * B * T * n
+    print(f"K1 B={B} T={T} in={in_f} out={out_f}: {ms*1e3:8.1f} us  write {wbytes/ms/1e6:7.1f} GB/s  alg {(wbytes+rbytes)/ms/1e6:7.1f} GB/s  {flops/ms/1e9:6.1f} TFLOP/s")
+
+def bench_reduce(B, P):
+    base = torch.randn(B, P, device="cuda"); clip = torch.rand(B, device="cuda")
+    ws_b = nat.clip_reduce_workspace(B, P)
+    ws = torch.empty(max(ws_b // 4, 4), device="cuda")
+    summed = torch.zeros(P, device="cuda"); grad = torch.zeros(P, device="cuda")
+    v = nat.FlatView(base, 0, P)
+    ms = timeit(lambda: nat.clip_reduce_noise(v, clip, None, None, 1, 0, 1.0, 1.0 / B, summed, grad, B, ws))
+    print(f"K7 B={B} P={P}: {ms*1e3:8.1f} us  read {B*P*4/ms/1e6:7.1f} GB/s (ws {ws_b>>20} MiB)")
+
+if __name__ == "__main__":
+    which = sys.argv[1] if len(sys.argv) > 1 else "all"
+    if which in ("all", "k1"):
+        for B in (64, 1024):
+            bench_linear(B, 24, 400, 200)
+            bench_linear(B, 24, 208, 208)
+        bench_linear(1024, 24, 256, 128)
+        bench_linear(1024, 24, 512, 512)
+        bench_linear(1024, 24, 32, 128)
+        bench_linear(512, 48, 250, 1000)
+        bench_linear(512, 48, 500, 1000)
+        bench_linear(128, 256, 2048, 2048)
+        bench_linear(256, 256, 1024, 512)
+    if which in ("all", "k7"):
+        bench_reduce(64, 649408)
+        bench_reduce(1024, 824448)
+        bench_reduce(2048, 2830272)
+        bench_reduce(256, 12292096)
