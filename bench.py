@@ -1,0 +1,272 @@
+#!/usr/bin/env python3
+"""bench.py — DP-SGD training samples/s of the MI355X-native step (BASELINE.json metric).
+
+  python bench.py --gpus N --steps K --warmup W        (N>1: launched by torch.distributed.run, one rank per GPU)
+
+A "step" is one complete DP-SGD training step on a resident synthetic batch: zero_grad, forward, loss,
+backward (hooks -> per-sample-gradient kernels K1/K3/K4), optimizer.step (K6 clip factors, K7 clipped sum +
+Philox noise + scale, then Adam).  Workload at N=1 = BASELINE.json configs[1] (VAE, B=1024, T=24, 32 features,
+hidden 128); with N>1 every rank runs the same per-GPU batch (weak scaling), clipped sums are all-reduced as
+one flat buffer over RCCL and identical Philox noise is added on every rank.
+
+Printed JSON (rank 0, one line) also carries
+  roofline      the dominant kernel (K7 clip_reduce_noise): algorithmic bytes 4*P*B per launch / mean launch
+                duration measured with HIP events on the launch stream inside the timed region;
+  hot_path      K1..K7 alone, replayed from captured activations/backprops (no autograd, no Adam);
+  cpu_baseline  the oracle's torch-CPU restatement of the reference step (per-call einsum + accumulate,
+                two-pass clip), timed on this box's host cores on a bounded sample of the same workload.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6300 achievable
+MFMA_F32_PEAK_TFLOPS = 157.3
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--config", default="cfg2")
+    ap.add_argument("--batch", type=int, default=None, help="per-GPU batch (default: the config's)")
+    ap.add_argument("--physical-batch", type=int, default=None, help="max physical chunk (BatchMemoryManager)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-sample", type=int, default=None)
+    return ap.parse_args()
+
+
+class KernelTimer:
+    """Wraps one _native entry point with HIP events recorded on the launch stream."""
+
+    def __init__(self, native, name):
+        self.native, self.name = native, name
+        self.orig = getattr(native, name)
+        self.events = []
+        self.enabled = False
+        setattr(native, name, self)
+
+    def __call__(self, *a, **k):
+        if not self.enabled:
+            return self.orig(*a, **k)
+        e0 = torch.cuda.Event(enable_timing=True)
+        e1 = torch.cuda.Event(enable_timing=True)
+        e0.record()  # torch's current stream == the stream _native launches on
+        r = self.orig(*a, **k)
+        e1.record()
+        self.events.append((e0, e1))
+        return r
+
+    def mean_ms(self):
+        if not self.events:
+            return None
+        return sum(a.elapsed_time(b) for a, b in self.events) / len(self.events)
+
+    def total_ms(self):
+        return sum(a.elapsed_time(b) for a, b in self.events)
+
+
+def cpu_baseline(cfg_name, sample_B, budget_s=25.0):
+    """Reference op sequence on host cores (oracle = CPU restatement of the Opacus step)."""
+    from dp_timeautodiff_amd import workloads
+    from oracle import opacus_ref as O
+    cores = os.cpu_count() or 1
+    cores = min(cores, int(os.environ.get("OMP_NUM_THREADS", cores)))
+    torch.set_num_threads(cores)
+    wl = workloads.build(cfg_name, torch.device("cpu"), batch=sample_B)
+    gsm = O.OracleGradSampleModule(wl.model)
+    opt = O.OracleDPOptimizer(list(wl.model.parameters()), noise_multiplier=1.0, max_grad_norm=1.0,
+                              expected_batch_size=sample_B, generator=torch.Generator().manual_seed(3))
+    adam = torch.optim.Adam(wl.model.parameters(), lr=2e-4, weight_decay=1e-6)
+
+    def step():
+        opt.zero_grad()
+        wl.loss_fn(wl.model).backward()
+        opt.pre_step()
+        adam.step()
+
+    t0 = time.perf_counter()
+    step()  # warm-up
+    first = time.perf_counter() - t0
+    n = max(1, min(5, int(budget_s / max(first, 1e-3))))
+    t0 = time.perf_counter()
+    for _ in range(n):
+        step()
+    dt = (time.perf_counter() - t0) / n
+    return {"value": sample_B / dt, "unit": "samples/s", "cores": cores, "kind": "port",
+            "sample": f"{n} step(s) of {cfg_name} at batch {sample_B} (torch-CPU restatement of the Opacus step: "
+                      f"per-call einsum+accumulate, two-pass clip, per-parameter noise, Adam), {dt*1e3:.0f} ms/step"}
+
+
+def main():
+    args = parse()
+    rank = int(os.environ.get("RANK", 0))
+    world = int(os.environ.get("WORLD_SIZE", 1))
+    local = int(os.environ.get("LOCAL_RANK", 0))
+    if world != args.gpus and world > 1:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU (the product path has no CPU fallback)")
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group("nccl", device_id=dev)
+
+    from dp_timeautodiff_amd import _native, workloads
+    from dp_timeautodiff_amd.distributed import DifferentiallyPrivateDistributedDataParallel as DPDDP
+    from dp_timeautodiff_amd.grad_sample import GradSampleModule
+    from dp_timeautodiff_amd.optimizer import DistributedDPOptimizer, DPOptimizer
+    _native.load()
+
+    wl = workloads.build(args.config, dev, batch=args.batch, seed_offset=rank * 1000)
+    B = wl.B
+    phys = args.physical_batch or (512 if args.config == "cfg5" else B)
+    model = wl.model
+    if world > 1:
+        DPDDP(model)  # broadcasts rank-0 parameters
+    gsm = GradSampleModule(model)
+    adam = torch.optim.Adam(model.parameters(), lr=2e-4, weight_decay=1e-6)
+    cls = DistributedDPOptimizer if world > 1 else DPOptimizer
+    opt = cls(adam, noise_multiplier=1.0, max_grad_norm=1.0, expected_batch_size=B, noise_seed=3)
+    opt.attach_grad_sample_module(gsm)
+    chunks = [(lo, min(lo + phys, B)) for lo in range(0, B, phys)]
+
+    k7 = KernelTimer(_native, "clip_reduce_noise" if world == 1 else "clip_reduce")
+    k1 = KernelTimer(_native, "linear_grad_sample")
+
+    def step():
+        for ci, (lo, hi) in enumerate(chunks):
+            opt.signal_skip_step(do_skip=ci < len(chunks) - 1)
+            opt.zero_grad()
+            loss = wl.loss_fn(gsm, lo, hi)
+            loss.backward()
+            opt.step()
+        return loss
+
+    def sync():
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    sync()
+    k7.enabled = k1.enabled = True
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        loss = step()
+    sync()
+    dt = time.perf_counter() - t0
+    k7.enabled = k1.enabled = False
+    if dist is not None:
+        tmax = torch.tensor([dt], device=dev, dtype=torch.float64)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        dt = float(tmax.item())
+    final_loss = float(loss)
+
+    # ---- roofline of the dominant kernel (K7) ------------------------------------------------------------
+    P_arena = gsm.arena.P
+    k7_ms = k7.mean_ms()
+    rows_per_launch = B / len(chunks)
+    k7_bytes = 4.0 * P_arena * rows_per_launch  # each per-sample gradient element read once
+    roof = {"bound": "hbm", "kernel": "clip_reduce_kernel (K7: clipped sum + noise + scale)",
+            "achieved": k7_bytes / (k7_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "frac": k7_bytes / (k7_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "traffic": None,
+            "avg_launch_ms": k7_ms, "bytes_per_launch": k7_bytes}
+    k1_total_ms = k1.total_ms() / args.steps
+    k1_bytes = B * (4.0 * wl.n_params + wl.io_bytes_per_sample)
+    k1_roof = {"bound": "hbm", "kernel": "linear_gs_kernel (K1, all Linear layers of one step)",
+               "achieved": k1_bytes / (k1_total_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+               "frac": k1_bytes / (k1_total_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "ms_per_step": k1_total_ms,
+               "tflops": B * wl.flops_per_sample / (k1_total_ms * 1e-3) / 1e12,
+               "mfma_frac": B * wl.flops_per_sample / (k1_total_ms * 1e-3) / 1e12 / MFMA_F32_PEAK_TFLOPS}
+
+    # ---- hot path alone: K1..K7 replayed from captured (activation, backprop) pairs -------------------------
+    hot = None
+    if world == 1:
+        hot = hot_path(_native, gsm, opt, wl, chunks, steps=max(args.steps, 5))
+
+    ms = dt / args.steps * 1e3
+    out = {
+        "metric": "DP-SGD training samples/sec (whole node)", "value": world * B * args.steps / dt,
+        "unit": "samples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms,
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "config": {"workload": f"{args.config}: {workloads.CONFIGS[args.config]['desc']}",
+                   "per_gpu_batch": B, "global_batch": B * world, "physical_batch": phys,
+                   "params": wl.n_params, "parallelism": f"dp{world}",
+                   "step": "zero_grad+forward+backward(hooks: K1/K3/K4)+DPOptimizer.step(K6,K7)+Adam"},
+        "roofline": roof, "roofline_k1": k1_roof, "hot_path": hot, "final_loss": final_loss,
+    }
+    if rank == 0:
+        if not args.no_cpu_baseline and world == 1:
+            sample = args.cpu_sample or {"cfg2": 256, "cfg1": 64, "cfg3": 64, "cfg5": 8}.get(args.config, 64)
+            out["cpu_baseline"] = cpu_baseline(args.config, min(sample, B))
+        print(json.dumps(out), flush=True)
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+def hot_path(native, gsm, opt, wl, chunks, steps):
+    """Time K1..K7 alone on resident (A, G) pairs captured from one real step of the first chunk."""
+    captured = []
+    orig = {n: getattr(native, n) for n in ("linear_grad_sample", "embedding_grad_sample", "layernorm_grad_sample")}
+
+    def cap(name):
+        def f(*a):
+            captured.append((name, a))
+            return orig[name](*a)
+        return f
+
+    for n in orig:
+        setattr(native, n, cap(n))
+    lo, hi = chunks[0]
+    opt.signal_skip_step(do_skip=False)
+    opt.zero_grad()
+    wl.loss_fn(gsm, lo, hi).backward()
+    for n in orig:
+        setattr(native, n, orig[n])
+    arena = gsm.arena
+    Bc = hi - lo
+    inv = 1.0 / wl.B
+    ws = arena.ensure_workspace(Bc)
+    full = native.FlatView(arena.buf, 0, arena.P)
+
+    def replay():
+        for name, a in captured:
+            orig[name](*a)
+        native.clip_factors(arena.part, arena.n_slots, arena.clip, arena.norms, Bc, 1.0)
+        native.clip_reduce_noise(full, arena.clip, None, None, 3, 0, 1.0, inv, arena.summed, arena.grad, Bc, ws)
+
+    for _ in range(3):
+        replay()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(steps):
+        replay()
+    e1.record()
+    torch.cuda.synchronize()
+    ms = e0.elapsed_time(e1) / steps
+    opt.zero_grad()
+    bytes_ps = 8.0 * wl.n_params + wl.io_bytes_per_sample
+    sps = Bc / (ms * 1e-3)
+    return {"what": "K1..K7 only (per-sample grads from resident activations/backprops -> norms -> clip -> sum -> "
+                    "noise -> scale), one physical chunk", "batch": Bc, "ms": ms, "samples_per_s": sps,
+            "bytes_per_sample": bytes_ps, "hbm_GBs": sps * bytes_ps / 1e9, "hbm_frac": sps * bytes_ps / 1e9 / HBM_PEAK_GBS,
+            "mfma_tflops": sps * wl.flops_per_sample / 1e12,
+            "mfma_frac": sps * wl.flops_per_sample / 1e12 / MFMA_F32_PEAK_TFLOPS}
+
+
+if __name__ == "__main__":
+    main()
