@@ -13,7 +13,6 @@ Linear / Embedding / activations, so for it `fix` is a plain clone.
 from __future__ import annotations
 
 import copy
-import io
 from typing import List
 
 import torch
@@ -41,11 +40,8 @@ _INSTANCENORM = (nn.InstanceNorm1d, nn.InstanceNorm2d, nn.InstanceNorm3d)
 
 
 def clone_module(module: nn.Module) -> nn.Module:
-    """Deep clone through an in-memory save/load round trip (handles shared storage like Opacus does)."""
-    with io.BytesIO() as bytesio:
-        torch.save(module, bytesio)
-        bytesio.seek(0)
-        return torch.load(bytesio, weights_only=False)  # our own bytes, written two lines above
+    """Deep clone (parameters, buffers and submodule structure); the original is left untouched."""
+    return copy.deepcopy(module)
 
 
 def _replace(root: nn.Module, name: str, new: nn.Module) -> nn.Module:
