@@ -183,6 +183,8 @@ def main():
             "achieved": k7_bytes / (k7_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
             "frac": k7_bytes / (k7_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "traffic": None,
             "avg_launch_ms": k7_ms, "bytes_per_launch": k7_bytes}
+    traffic, traffic_src = pmc_traffic(args.config, B, len(chunks))
+    roof["traffic"], roof["traffic_source"] = traffic, traffic_src
     k1_total_ms = k1.total_ms() / args.steps
     k1_bytes = B * (4.0 * wl.n_params + wl.io_bytes_per_sample)
     k1_roof = {"bound": "hbm", "kernel": "linear_gs_kernel (K1, all Linear layers of one step)",
@@ -215,6 +217,22 @@ def main():
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
+
+
+def pmc_traffic(config, B, n_chunks):
+    """HBM bytes per K7 launch from the committed rocprofv3 --pmc passes (FETCH_SIZE x2 + WRITE_SIZE, collected in
+    separate runs by tools/hotpath_replay.py + tools/pmc_summary.py at this config's default batch)."""
+    import glob
+    from dp_timeautodiff_amd import workloads
+    if n_chunks != 1 or B != workloads.CONFIGS[config]["B"]:
+        return None, None
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", f"r*_{config}_pmc_traffic.json")))
+    if not files:
+        return None, None
+    k = json.load(open(files[-1]))["kernels"]
+    tot = sum(v["fetch_bytes"] + v["write_bytes"] for n, v in k.items()
+              if n.startswith("clip_reduce_kernel") or n.startswith("finalize_kernel"))
+    return tot, os.path.relpath(files[-1], ROOT)
 
 
 def hot_path(native, gsm, opt, wl, chunks, steps):

@@ -1,0 +1,25 @@
+"""Summarise rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes into profiles/<tag>_pmc_traffic.json.
+FETCH_SIZE on gfx950 reports 1/2 of the bytes of a wide coalesced read (MI355X_MICROARCH.md §HBM): doubled here.
+usage: python tools/pmc_summary.py <fetch_dir> <write_dir> <tag>"""
+import collections, csv, glob, json, os, sys
+
+def load(d):
+    f = glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True)[0]
+    agg = collections.OrderedDict()
+    for r in csv.DictReader(open(f)):
+        k = r["Kernel_Name"]
+        if "(anonymous namespace)::" not in k or "at::native" in k:
+            continue
+        short = k.split("(anonymous namespace)::")[1].split("(")[0]
+        agg.setdefault(short, []).append(float(r["Counter_Value"]))
+    return {k: sum(v) / len(v) for k, v in agg.items()}, {k: len(v) for k, v in agg.items()}
+
+fetch, n = load(sys.argv[1])
+write, _ = load(sys.argv[2])
+out = {"note": "per-launch means; FETCH_SIZE KB x 2 (gfx950 wide-read correction) x 1024; WRITE_SIZE KB x 1024",
+       "kernels": {k: {"launches": n[k], "fetch_bytes": fetch[k] * 2 * 1024, "write_bytes": write.get(k, 0.0) * 1024}
+                   for k in fetch}}
+root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+json.dump(out, open(os.path.join(root, "profiles", f"{sys.argv[3]}_pmc_traffic.json"), "w"), indent=1)
+for k, v in out["kernels"].items():
+    print(f"{k:36s} n={v['launches']:4d} fetch {v['fetch_bytes']/1e6:10.2f} MB  write {v['write_bytes']/1e6:10.2f} MB")
