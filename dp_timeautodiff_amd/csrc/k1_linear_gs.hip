@@ -2,35 +2,38 @@
 //
 //   GSw[b,o,i] = sum_t (g_scale*G[b,t,o]) * A[b,t,i]       GSb[b,o] = sum_t g_scale*G[b,t,o]
 //
-// One workgroup (4 waves) owns a BM x BN tile of ONE sample's [out, in] gradient.  The T x BM
-// slice of G and the T x BN slice of A are staged through LDS in chunks of TK time steps with
-// 16-byte global loads (scaled by g_scale on the way in, as Opacus scales backprops before its
-// einsum); each wave feeds v_mfma_f32_32x32x2_f32 straight from LDS (one ds_read_b32 per operand
-// per lane: A-operand rows = o, B-operand cols = i, both unit-stride in LDS -> conflict-free).
-// f32-in MFMA is an exact k-ordered fmaf chain, so the result is deterministic.
-// The kernel is output-write bound at the reference's T=24 (AI = T/2 flop per byte): the
-// accumulator layout (col = lane&31, rows in registers) makes every store instruction write two
-// full 128-byte row segments.
-// Epilogue also emits sum(GS^2) of the tile (+ the bias slice in column-tile 0) as ONE float per
-// (sample, tile) — the norm pass of DPOptimizer.clip_and_accumulate never re-reads the gradient.
+// "Operand-resident" structure (round-1 lab result, tools/lab/k1_lab.hip): the kernel is bound by HBM
+// *writes* at the reference's T=24 (AI = T/2 flop per byte), and on CDNA4 a CU's vector-memory pipe is
+// in order across its waves — operand loads queue behind other waves' pending stores.  So the load
+// volume per output byte is what has to shrink: one workgroup (8 waves) stages a [TK x 128] slice of G and
+// a [TK x 256] slice of A of ONE sample in LDS (operand bytes per output byte = T*(1/128+1/256) = 0.28
+// instead of 0.56 for a 64x128 tile), then every wave runs the 12 MFMAs (v_mfma_f32_32x32x2_f32, fed by
+// unit-stride conflict-free ds_read_b32) of its 32x64 micro-tiles and streams the accumulators out.
+// The accumulator layout (col = lane&31, rows in registers) makes every store instruction two full
+// 128-byte row segments; when the row stride is a multiple of 128 B those are whole cache lines and are
+// written non-temporally (the arena is read back exactly once, by K7, long after it left the caches):
+// 3.0 -> 5.1 TB/s on a [512 x 512] layer at B=1024.
+// T > 32 is handled by K-chunks of 32 steps with the accumulators kept in registers across chunks.
+// f32-in MFMA is an exact k-ordered fmaf chain and all reductions have a fixed order: deterministic.
+// The epilogue emits sum(GS^2) of the tile (+ the bias slice in column-tile 0) as ONE float per
+// (sample, tile), so the norm pass of DPOptimizer.clip_and_accumulate never re-reads the gradient.
 //
-// Grid: 1-D, XCD-aware: blocks id and id+8 share an XCD (round-robin dispatch), so all tiles of
-// sample b are given ids congruent to b mod 8 and consecutive in id/8 — a sample's A/G slices
-// are then fetched into ONE XCD's L2 and re-read there by its other tiles.  (Placement is used
-// for speed only; results do not depend on it.)
+// Grid: 1-D, XCD-aware: blocks id and id+8 share an XCD (round-robin dispatch), so all tiles of sample b get
+// ids congruent to b mod 8 and consecutive in id/8 — a sample's A/G slices are then fetched into ONE XCD's
+// L2 and re-read there by its other tiles.  (Placement is used for speed only; results do not depend on it.)
 #include "dpk_common.h"
 
 namespace {
 
 constexpr int TK = 32;  // time steps staged per LDS chunk (even)
 
-template <int W>
+template <int W, int NTHR>
 __device__ __forceinline__ void stage_rows(float* __restrict__ s, const float* __restrict__ g, int t0, int rows,
                                            int T, int c0, int dim, float scale, bool vec) {
     // s[rows][W]  <-  scale * g[t0 + r][c0 + c]   (zero outside [0,T) x [0,dim))
     if (vec) {
         constexpr int W4 = W / 4;
-        for (int idx = threadIdx.x; idx < rows * W4; idx += blockDim.x) {
+        for (int idx = threadIdx.x; idx < rows * W4; idx += NTHR) {
             const int r = idx / W4;
             const int c = (idx - r * W4) * 4;
             const int t = t0 + r;
@@ -40,7 +43,7 @@ __device__ __forceinline__ void stage_rows(float* __restrict__ s, const float* _
             *reinterpret_cast<f32x4*>(s + r * W + c) = v;
         }
     } else {
-        for (int idx = threadIdx.x; idx < rows * W; idx += blockDim.x) {
+        for (int idx = threadIdx.x; idx < rows * W; idx += NTHR) {
             const int r = idx / W;
             const int c = idx - r * W;
             const int t = t0 + r;
@@ -51,19 +54,27 @@ __device__ __forceinline__ void stage_rows(float* __restrict__ s, const float* _
     }
 }
 
-// WM x WN waves (WM*WN == 4); each wave owns NT 32x32 MFMA tiles side by side along `in`.
-template <int WM, int WN, int NT>
-__global__ void __launch_bounds__(256) linear_gs_kernel(const float* __restrict__ A, const float* __restrict__ G,
-                                                        float* __restrict__ GSw, float* __restrict__ GSb,
-                                                        float* __restrict__ normsq_part, int64_t part_stride,
-                                                        int slot0, int B, int T, int in_f, int out_f,
-                                                        int64_t gs_stride, float g_scale, int tiles_m,
-                                                        int tiles_n, int vecA, int vecG) {
-    constexpr int BM = 32 * WM;
-    constexpr int BN = 32 * WN * NT;
-    __shared__ __attribute__((aligned(16))) float sG[TK * BM];
-    __shared__ __attribute__((aligned(16))) float sA[TK * BN];
-    __shared__ float red[4];
+// NW waves; block tile RS (out) x CS (in); a wave "unit" is one 32-row strip x NT adjacent 32-col MFMA tiles.
+// STREAM (T <= TK, one chunk): a wave computes a unit and stores it at once (16 live accumulator registers per
+// MFMA tile, stores of unit u overlap the MFMAs of unit u+1 of other waves); otherwise the accumulators of all
+// of a wave's units persist across the K-chunks.
+template <int NW, int RS, int CS, int NT, bool STREAM>
+__global__ void __launch_bounds__(NW * 64) linear_gs_kernel(const float* __restrict__ A, const float* __restrict__ G,
+                                                           float* __restrict__ GSw, float* __restrict__ GSb,
+                                                           float* __restrict__ normsq_part, int64_t part_stride,
+                                                           int slot0, int B, int T, int in_f, int out_f,
+                                                           int64_t gs_stride, float g_scale, int tiles_m,
+                                                           int tiles_n, int vecA, int vecG, int nt_store) {
+    constexpr int NTHR = NW * 64;
+    constexpr int NCG = CS / (32 * NT);        // column groups per tile
+    constexpr int UNITS = (RS / 32) * NCG;
+    constexpr int U = (UNITS + NW - 1) / NW;   // units per wave
+    static_assert(RS % 32 == 0 && CS % (32 * NT) == 0, "tile must be a whole number of MFMA units");
+    extern __shared__ __attribute__((aligned(16))) float smem[];  // [rows][RS] G slice, [rows][CS] A slice, red[NW]
+    const int lds_rows = STREAM ? ((T + 1) & ~1) : TK;
+    float* sG = smem;
+    float* sA = smem + lds_rows * RS;
+    float* red = sA + lds_rows * CS;
 
     // ---- XCD-aware block -> (sample, tile) map -------------------------------------------------
     const int ntile = tiles_m * tiles_n;
@@ -75,62 +86,26 @@ __global__ void __launch_bounds__(256) linear_gs_kernel(const float* __restrict_
     if (b >= B) return;  // whole block leaves together (uniform)
     const int tm = tile / tiles_n;
     const int tn = tile - tm * tiles_n;
-    const int m0 = tm * BM;
-    const int n0 = tn * BN;
+    const int m0 = tm * RS;
+    const int n0 = tn * CS;
 
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
-    const int wm = wave % WM;
-    const int wn = wave / WM;
     const int l31 = lane & 31;
     const int lh = lane >> 5;
 
     const float* Ab = A + (int64_t)b * T * in_f;
     const float* Gb = G + (int64_t)b * T * out_f;
 
-    // a wave whose whole 32-row strip or whose every 32-col tile is out of range does no MFMA
-    const int wrow0 = m0 + wm * 32;
-    const int wcol0 = n0 + wn * (32 * NT);
-    const bool wave_live = (wrow0 < out_f) && (wcol0 < in_f);
-
-    f32x16 acc[NT];
-#pragma unroll
-    for (int j = 0; j < NT; ++j)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
-
     float bias_acc = 0.f;
-    const bool do_bias = (GSb != nullptr) && (tn == 0) && (threadIdx.x < BM);
-
-    for (int t0 = 0; t0 < T; t0 += TK) {
-        int rows = T - t0;
-        if (rows > TK) rows = TK;
-        const int rows2 = (rows + 1) & ~1;  // MFMA consumes k in pairs; the pad row is zero-filled
-        stage_rows<BM>(sG, Gb, t0, rows2, T, m0, out_f, g_scale, vecG != 0);
-        stage_rows<BN>(sA, Ab, t0, rows2, T, n0, in_f, 1.0f, vecA != 0);
-        __syncthreads();
-        if (wave_live) {
-            const float* pg = sG + lh * BM + wm * 32 + l31;
-            const float* pa = sA + lh * BN + wn * (32 * NT) + l31;
-            for (int kk = 0; kk < rows2; kk += 2) {
-                const float a = pg[kk * BM];
-#pragma unroll
-                for (int j = 0; j < NT; ++j) {
-                    const float bv = pa[kk * BN + j * 32];
-                    acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, bv, acc[j], 0, 0, 0);
-                }
-            }
-        }
-        if (do_bias) {
-            for (int r = 0; r < rows; ++r) bias_acc += sG[r * BM + threadIdx.x];
-        }
-        __syncthreads();
-    }
-
-    // ---- epilogue: store the tile, accumulate its squared norm ----------------------------------
+    const bool do_bias = (GSb != nullptr) && (tn == 0) && ((int)threadIdx.x < RS);
     float sq = 0.f;
-    if (wave_live) {
-        float* out = GSw + (int64_t)b * gs_stride;
+    float* out = GSw + (int64_t)b * gs_stride;
+
+    auto store_unit = [&](const f32x16 (&acc)[NT], int u) {
+        const int mr = u / NCG, cg = u - mr * NCG;
+        const int wrow0 = m0 + mr * 32;
+        const int wcol0 = n0 + cg * (32 * NT);
 #pragma unroll
         for (int j = 0; j < NT; ++j) {
             const int col = wcol0 + j * 32 + l31;
@@ -140,40 +115,107 @@ __global__ void __launch_bounds__(256) linear_gs_kernel(const float* __restrict_
                     const int row = wrow0 + (r & 3) + 8 * (r >> 2) + 4 * lh;
                     if (row < out_f) {
                         const float v = acc[j][r];
-                        out[(int64_t)row * in_f + col] = v;
+                        float* p = out + (int64_t)row * in_f + col;
+                        if (nt_store)
+                            __builtin_nontemporal_store(v, p);
+                        else
+                            *p = v;
                         sq += v * v;
                     }
                 }
             }
+        }
+    };
+
+    if constexpr (STREAM) {
+        const int rows2 = (T + 1) & ~1;  // MFMA consumes k in pairs; the pad row is zero-filled
+        stage_rows<RS, NTHR>(sG, Gb, 0, rows2, T, m0, out_f, g_scale, vecG != 0);
+        stage_rows<CS, NTHR>(sA, Ab, 0, rows2, T, n0, in_f, 1.0f, vecA != 0);
+        __syncthreads();
+        for (int u = wave; u < UNITS; u += NW) {
+            const int mr = u / NCG, cg = u - mr * NCG;
+            if (m0 + mr * 32 >= out_f || n0 + cg * (32 * NT) >= in_f) continue;
+            f32x16 acc[NT];
+#pragma unroll
+            for (int j = 0; j < NT; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
+            const float* pg = sG + lh * RS + mr * 32 + l31;
+            const float* pa = sA + lh * CS + cg * (32 * NT) + l31;
+            for (int kk = 0; kk < rows2; kk += 2) {
+                const float a = pg[kk * RS];
+#pragma unroll
+                for (int j = 0; j < NT; ++j)
+                    acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, pa[kk * CS + j * 32], acc[j], 0, 0, 0);
+            }
+            store_unit(acc, u);
+        }
+        if (do_bias) {
+            for (int r = 0; r < T; ++r) bias_acc += sG[r * RS + threadIdx.x];
+        }
+    } else {
+        f32x16 acc[U][NT];
+#pragma unroll
+        for (int k = 0; k < U; ++k)
+#pragma unroll
+            for (int j = 0; j < NT; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[k][j][r] = 0.f;
+        for (int t0 = 0; t0 < T; t0 += TK) {
+            int rows = T - t0;
+            if (rows > TK) rows = TK;
+            const int rows2 = (rows + 1) & ~1;
+            stage_rows<RS, NTHR>(sG, Gb, t0, rows2, T, m0, out_f, g_scale, vecG != 0);
+            stage_rows<CS, NTHR>(sA, Ab, t0, rows2, T, n0, in_f, 1.0f, vecA != 0);
+            __syncthreads();
+#pragma unroll
+            for (int k = 0; k < U; ++k) {
+                const int u = wave + k * NW;
+                const int mr = u / NCG, cg = u - mr * NCG;
+                const bool live = (u < UNITS) && (m0 + mr * 32 < out_f) && (n0 + cg * (32 * NT) < in_f);
+                if (live) {
+                    const float* pg = sG + lh * RS + mr * 32 + l31;
+                    const float* pa = sA + lh * CS + cg * (32 * NT) + l31;
+                    for (int kk = 0; kk < rows2; kk += 2) {
+                        const float a = pg[kk * RS];
+#pragma unroll
+                        for (int j = 0; j < NT; ++j)
+                            acc[k][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, pa[kk * CS + j * 32], acc[k][j], 0, 0, 0);
+                    }
+                }
+            }
+            if (do_bias) {
+                for (int r = 0; r < rows; ++r) bias_acc += sG[r * RS + threadIdx.x];
+            }
+            __syncthreads();
+        }
+#pragma unroll
+        for (int k = 0; k < U; ++k) {
+            const int u = wave + k * NW;
+            const int mr = u / NCG, cg = u - mr * NCG;
+            if (u < UNITS && m0 + mr * 32 < out_f && n0 + cg * (32 * NT) < in_f) store_unit(acc[k], u);
         }
     }
     if (do_bias && m0 + (int)threadIdx.x < out_f) {
         GSb[(int64_t)b * gs_stride + m0 + threadIdx.x] = bias_acc;
         sq += bias_acc * bias_acc;
     }
-    const float tot = block_sum<4>(sq, red);
+    const float tot = block_sum<NW>(sq, red);
     if (threadIdx.x == 0) normsq_part[(int64_t)b * part_stride + slot0 + tile] = tot;
 }
 
 struct Plan {
-    int wm, wn, nt;  // waves along out, waves along in, MFMA tiles per wave along in
-    int bm, bn;
+    int id;      // which instantiation
+    int rs, cs;  // block tile (out x in)
 };
 
-// Tile-shape choice: keep the block tile as large as the layer allows (less operand re-staging
-// per output byte) but never wider than the layer (idle waves).
+// Tile choice: the widest tile the layer fills (fewest operand bytes per output byte) ...
 inline Plan pick_plan(int in_f, int out_f) {
-    Plan p;
-    if (in_f <= 32) {
-        p = {4, 1, 1, 128, 32};
-    } else if (out_f <= 32) {
-        p = (in_f <= 128) ? Plan{1, 4, 1, 32, 128} : Plan{1, 4, 2, 32, 256};
-    } else if (in_f <= 64) {
-        p = {2, 2, 1, 64, 64};
-    } else {
-        p = {2, 2, 2, 64, 128};
-    }
-    return p;
+    if (out_f <= 32) return in_f > 64 ? Plan{3, 32, 256} : Plan{2, 128, 64};
+    if (in_f <= 32) return Plan{4, 128, 32};
+    if (in_f <= 64) return Plan{2, 128, 64};
+    if (in_f <= 128) return Plan{1, 128, 128};
+    return Plan{0, 128, 256};
 }
 
 }  // namespace
@@ -181,8 +223,8 @@ inline Plan pick_plan(int in_f, int out_f) {
 extern "C" int dpk_linear_slots(int in_features, int out_features) {
     if (in_features <= 0 || out_features <= 0) return DPK_EINVAL;
     const Plan p = pick_plan(in_features, out_features);
-    const int tiles_m = (out_features + p.bm - 1) / p.bm;
-    const int tiles_n = (in_features + p.bn - 1) / p.bn;
+    const int tiles_m = (out_features + p.rs - 1) / p.rs;
+    const int tiles_n = (in_features + p.cs - 1) / p.cs;
     return tiles_m * tiles_n;
 }
 
@@ -194,29 +236,38 @@ extern "C" int dpk_linear_grad_sample(const float* A, const float* G, float* GSw
     if (gs_stride < (int64_t)in_f * out_f) return DPK_EINVAL;
     if (B == 0) return DPK_OK;
     const Plan p = pick_plan(in_f, out_f);
-    const int tiles_m = (out_f + p.bm - 1) / p.bm;
-    const int tiles_n = (in_f + p.bn - 1) / p.bn;
+    const int tiles_m = (out_f + p.rs - 1) / p.rs;
+    const int tiles_n = (in_f + p.cs - 1) / p.cs;
     const int64_t ntile = (int64_t)tiles_m * tiles_n;
     if (slot0 + ntile > part_stride) return DPK_ESLOTS;
     const int64_t nblk = ((int64_t)(B + 7) / 8) * 8 * ntile;
     if (nblk > 0x7fffffffLL) return DPK_ERANGE;
     const int vecA = (in_f % 4 == 0) && dpk_aligned16(A);
     const int vecG = (out_f % 4 == 0) && dpk_aligned16(G);
+    // whole 128-byte lines per store segment: row stride and every row start multiples of 32 floats
+    const int nt_store = (in_f % 32 == 0) && (gs_stride % 32 == 0) && ((((uintptr_t)GSw) & 127u) == 0);
     hipStream_t s = (hipStream_t)stream;
-    dim3 grid((unsigned)nblk), block(256);
-#define DPK_K1_LAUNCH(WM, WN, NT)                                                                           \
-    hipLaunchKernelGGL((linear_gs_kernel<WM, WN, NT>), grid, block, 0, s, A, G, GSw, GSb, normsq_part,       \
-                       part_stride, slot0, B, T, in_f, out_f, gs_stride, g_scale, tiles_m, tiles_n, vecA, vecG)
-    if (p.wm == 4) {
-        DPK_K1_LAUNCH(4, 1, 1);
-    } else if (p.wm == 1 && p.nt == 1) {
-        DPK_K1_LAUNCH(1, 4, 1);
-    } else if (p.wm == 1) {
-        DPK_K1_LAUNCH(1, 4, 2);
-    } else if (p.nt == 1) {
-        DPK_K1_LAUNCH(2, 2, 1);
-    } else {
-        DPK_K1_LAUNCH(2, 2, 2);
+    dim3 grid((unsigned)nblk);
+    const bool stream_mode = T <= TK;
+    const int lds_rows = stream_mode ? ((T + 1) & ~1) : TK;
+#define DPK_K1_LAUNCH(NW, RS, CS, NT)                                                                          \
+    do {                                                                                                       \
+        const size_t lds = ((size_t)lds_rows * (RS + CS) + NW) * sizeof(float);                                \
+        if (stream_mode)                                                                                       \
+            hipLaunchKernelGGL((linear_gs_kernel<NW, RS, CS, NT, true>), grid, dim3(NW * 64), lds, s, A, G, GSw, \
+                               GSb, normsq_part, part_stride, slot0, B, T, in_f, out_f, gs_stride, g_scale,      \
+                               tiles_m, tiles_n, vecA, vecG, nt_store);                                          \
+        else                                                                                                   \
+            hipLaunchKernelGGL((linear_gs_kernel<NW, RS, CS, NT, false>), grid, dim3(NW * 64), lds, s, A, G,     \
+                               GSw, GSb, normsq_part, part_stride, slot0, B, T, in_f, out_f, gs_stride, g_scale, \
+                               tiles_m, tiles_n, vecA, vecG, nt_store);                                          \
+    } while (0)
+    switch (p.id) {
+        case 0: DPK_K1_LAUNCH(8, 128, 256, 2); break;
+        case 1: DPK_K1_LAUNCH(8, 128, 128, 2); break;
+        case 2: DPK_K1_LAUNCH(4, 128, 64, 1); break;
+        case 3: DPK_K1_LAUNCH(4, 32, 256, 2); break;
+        default: DPK_K1_LAUNCH(4, 128, 32, 1); break;
     }
 #undef DPK_K1_LAUNCH
     return dpk_launch_status();

@@ -1,0 +1,564 @@
+// K1 lab: ablations / variants of the per-sample Linear grad kernel, timed with hipEvents.
+// build: hipcc -O3 -std=c++17 --offload-arch=gfx950 -o tools/lab/k1_lab tools/lab/k1_lab.hip
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <cstdlib>
+#include <vector>
+#include <cmath>
+#include <cstring>
+#include <dlfcn.h>
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+#define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("HIP error %s at %d\n", hipGetErrorString(e), __LINE__); exit(1);} } while (0)
+
+constexpr int TK = 32;
+
+template <int W>
+__device__ __forceinline__ void stage_rows(float* __restrict__ s, const float* __restrict__ g, int t0, int rows,
+                                           int T, int c0, int dim, float scale) {
+    constexpr int W4 = W / 4;
+    for (int idx = threadIdx.x; idx < rows * W4; idx += blockDim.x) {
+        const int r = idx / W4;
+        const int c = (idx - r * W4) * 4;
+        const int t = t0 + r;
+        f32x4 v = {0.f, 0.f, 0.f, 0.f};
+        if (t < T && c0 + c < dim) v = *reinterpret_cast<const f32x4*>(g + (int64_t)t * dim + c0 + c);
+        v *= scale;
+        *reinterpret_cast<f32x4*>(s + r * W + c) = v;
+    }
+}
+
+// VAR: 0 = baseline, 1 = no MFMA (stores only), 2 = no stores (MFMA + staging), 3 = no staging+no mfma (stores only, no loads)
+// 4 = XCD map off (plain id mapping)
+template <int WM, int WN, int NT, int VAR>
+__global__ void __launch_bounds__(256) k1_base(const float* __restrict__ A, const float* __restrict__ G,
+                                               float* __restrict__ GSw, int B, int T, int in_f, int out_f,
+                                               int64_t gs_stride, float g_scale, int tiles_m, int tiles_n,
+                                               float* __restrict__ part) {
+    constexpr int BM = 32 * WM;
+    constexpr int BN = 32 * WN * NT;
+    __shared__ __attribute__((aligned(16))) float sG[TK * BM];
+    __shared__ __attribute__((aligned(16))) float sA[TK * BN];
+    const int ntile = tiles_m * tiles_n;
+    const int64_t id = blockIdx.x;
+    int b, tile;
+    if (VAR == 4) { b = (int)(id / ntile); tile = (int)(id % ntile); }
+    else { const int xcd = (int)(id & 7); const int64_t q = id >> 3; b = (int)(q / ntile) * 8 + xcd; tile = (int)(q % ntile); }
+    if (b >= B) return;
+    const int tm = tile / tiles_n, tn = tile - tm * tiles_n;
+    const int m0 = tm * BM, n0 = tn * BN;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int wm = wave % WM, wn = wave / WM, l31 = lane & 31, lh = lane >> 5;
+    const float* Ab = A + (int64_t)b * T * in_f;
+    const float* Gb = G + (int64_t)b * T * out_f;
+    const int wrow0 = m0 + wm * 32, wcol0 = n0 + wn * (32 * NT);
+    const bool wave_live = (wrow0 < out_f) && (wcol0 < in_f);
+    f32x16 acc[NT];
+    for (int j = 0; j < NT; ++j) for (int r = 0; r < 16; ++r) acc[j][r] = (VAR == 1 || VAR == 3) ? (float)(lane + r) : 0.f;
+    for (int t0 = 0; t0 < T; t0 += TK) {
+        int rows = T - t0; if (rows > TK) rows = TK;
+        const int rows2 = (rows + 1) & ~1;
+        if (VAR != 3) {
+            stage_rows<BM>(sG, Gb, t0, rows2, T, m0, out_f, g_scale);
+            stage_rows<BN>(sA, Ab, t0, rows2, T, n0, in_f, 1.0f);
+            __syncthreads();
+        }
+        if (wave_live && VAR != 1 && VAR != 3) {
+            const float* pg = sG + lh * BM + wm * 32 + l31;
+            const float* pa = sA + lh * BN + wn * (32 * NT) + l31;
+            for (int kk = 0; kk < rows2; kk += 2) {
+                const float a = pg[kk * BM];
+#pragma unroll
+                for (int j = 0; j < NT; ++j) acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, pa[kk * BN + j * 32], acc[j], 0, 0, 0);
+            }
+        }
+        if (VAR == 1) { // keep the staged data alive
+            if (sG[threadIdx.x] == 123.456f) acc[0][0] += 1.f;
+        }
+        if (VAR != 3) __syncthreads();
+    }
+    float sq = 0.f;
+    if (wave_live) {
+        float* out = GSw + (int64_t)b * gs_stride;
+#pragma unroll
+        for (int j = 0; j < NT; ++j) {
+            const int col = wcol0 + j * 32 + l31;
+            if (col < in_f) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int row = wrow0 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                    if (row < out_f) {
+                        const float v = acc[j][r];
+                        if (VAR != 2) out[(int64_t)row * in_f + col] = v;
+                        sq += v * v;
+                    }
+                }
+            }
+        }
+    }
+    if (VAR == 2) { if (sq == 1.2345f) part[b] = sq; }
+    else {
+        for (int off = 32; off >= 1; off >>= 1) sq += __shfl_xor(sq, off, 64);
+        if (lane == 0) atomicAdd(&part[(int64_t)b * 64 + (tile & 63)], 0.f * sq);  // cheap stand-in for the partial write
+    }
+}
+
+// Variant T: transposed MFMA orientation -> each lane holds 4 consecutive `in` columns -> 16-byte stores.
+// MFMA A-operand rows = in index (from sA), B-operand cols = out index (from sG).
+// D[row=i][col=o]: lane (l31 = o, lh), reg r -> i = (r&3) + 8*(r>>2) + 4*lh ; regs 4g..4g+3 are 4 consecutive i.
+template <int WM, int WN, int NT, int VAR>
+__global__ void __launch_bounds__(256) k1_tr(const float* __restrict__ A, const float* __restrict__ G,
+                                             float* __restrict__ GSw, int B, int T, int in_f, int out_f,
+                                             int64_t gs_stride, float g_scale, int tiles_m, int tiles_n,
+                                             float* __restrict__ part) {
+    constexpr int BM = 32 * WM;
+    constexpr int BN = 32 * WN * NT;
+    __shared__ __attribute__((aligned(16))) float sG[TK * BM];
+    __shared__ __attribute__((aligned(16))) float sA[TK * BN];
+    const int ntile = tiles_m * tiles_n;
+    const int64_t id = blockIdx.x;
+    const int xcd = (int)(id & 7); const int64_t q = id >> 3;
+    const int b = (int)(q / ntile) * 8 + xcd; const int tile = (int)(q % ntile);
+    if (b >= B) return;
+    const int tm = tile / tiles_n, tn = tile - tm * tiles_n;
+    const int m0 = tm * BM, n0 = tn * BN;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int wm = wave % WM, wn = wave / WM, l31 = lane & 31, lh = lane >> 5;
+    const float* Ab = A + (int64_t)b * T * in_f;
+    const float* Gb = G + (int64_t)b * T * out_f;
+    const int wrow0 = m0 + wm * 32, wcol0 = n0 + wn * (32 * NT);
+    const bool wave_live = (wrow0 < out_f) && (wcol0 < in_f);
+    f32x16 acc[NT];
+    for (int j = 0; j < NT; ++j) for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
+    for (int t0 = 0; t0 < T; t0 += TK) {
+        int rows = T - t0; if (rows > TK) rows = TK;
+        const int rows2 = (rows + 1) & ~1;
+        stage_rows<BM>(sG, Gb, t0, rows2, T, m0, out_f, g_scale);
+        stage_rows<BN>(sA, Ab, t0, rows2, T, n0, in_f, 1.0f);
+        __syncthreads();
+        if (wave_live) {
+            const float* pg = sG + lh * BM + wm * 32 + l31;
+            const float* pa = sA + lh * BN + wn * (32 * NT) + l31;
+            for (int kk = 0; kk < rows2; kk += 2) {
+                const float g = pg[kk * BM];
+#pragma unroll
+                for (int j = 0; j < NT; ++j) acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(pa[kk * BN + j * 32], g, acc[j], 0, 0, 0);
+            }
+        }
+        __syncthreads();
+    }
+    float sq = 0.f;
+    if (wave_live) {
+        const int row = wrow0 + l31;  // o
+        float* out = GSw + (int64_t)b * gs_stride + (int64_t)row * in_f;
+        if (row < out_f) {
+#pragma unroll
+            for (int j = 0; j < NT; ++j) {
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const int col = wcol0 + j * 32 + 8 * g + 4 * lh;
+                    if (col < in_f) {  // in_f % 4 == 0 assumed in this variant
+                        f32x4 v = {acc[j][4 * g], acc[j][4 * g + 1], acc[j][4 * g + 2], acc[j][4 * g + 3]};
+                        *reinterpret_cast<f32x4*>(out + col) = v;
+                        sq += v.x * v.x + v.y * v.y + v.z * v.z + v.w * v.w;
+                    }
+                }
+            }
+        }
+    }
+    for (int off = 32; off >= 1; off >>= 1) sq += __shfl_xor(sq, off, 64);
+    if (lane == 0) atomicAdd(&part[(int64_t)b * 64 + (tile & 63)], 0.f * sq);
+}
+
+// Variant L: epilogue through LDS -> whole-row 16-byte stores (each wave writes its 32 x (32*NT) tile; rows contiguous)
+template <int WM, int WN, int NT>
+__global__ void __launch_bounds__(256) k1_lds(const float* __restrict__ A, const float* __restrict__ G,
+                                              float* __restrict__ GSw, int B, int T, int in_f, int out_f,
+                                              int64_t gs_stride, float g_scale, int tiles_m, int tiles_n,
+                                              float* __restrict__ part) {
+    constexpr int BM = 32 * WM;
+    constexpr int BN = 32 * WN * NT;
+    constexpr int WT = 32 * NT;            // wave tile width
+    constexpr int LDW = WT + 4;            // padded row (floats)
+    constexpr int STAGE = TK * (BM + BN);
+    constexpr int EPI = 4 * 32 * LDW;
+    __shared__ __attribute__((aligned(16))) float smem[(STAGE > EPI ? STAGE : EPI)];
+    float* sG = smem; float* sA = smem + TK * BM;
+    const int ntile = tiles_m * tiles_n;
+    const int64_t id = blockIdx.x;
+    const int xcd = (int)(id & 7); const int64_t q = id >> 3;
+    const int b = (int)(q / ntile) * 8 + xcd; const int tile = (int)(q % ntile);
+    if (b >= B) return;
+    const int tm = tile / tiles_n, tn = tile - tm * tiles_n;
+    const int m0 = tm * BM, n0 = tn * BN;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int wm = wave % WM, wn = wave / WM, l31 = lane & 31, lh = lane >> 5;
+    const float* Ab = A + (int64_t)b * T * in_f;
+    const float* Gb = G + (int64_t)b * T * out_f;
+    const int wrow0 = m0 + wm * 32, wcol0 = n0 + wn * WT;
+    const bool wave_live = (wrow0 < out_f) && (wcol0 < in_f);
+    f32x16 acc[NT];
+    for (int j = 0; j < NT; ++j) for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
+    for (int t0 = 0; t0 < T; t0 += TK) {
+        int rows = T - t0; if (rows > TK) rows = TK;
+        const int rows2 = (rows + 1) & ~1;
+        stage_rows<BM>(sG, Gb, t0, rows2, T, m0, out_f, g_scale);
+        stage_rows<BN>(sA, Ab, t0, rows2, T, n0, in_f, 1.0f);
+        __syncthreads();
+        if (wave_live) {
+            const float* pg = sG + lh * BM + wm * 32 + l31;
+            const float* pa = sA + lh * BN + wn * WT + l31;
+            for (int kk = 0; kk < rows2; kk += 2) {
+                const float a = pg[kk * BM];
+#pragma unroll
+                for (int j = 0; j < NT; ++j) acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, pa[kk * BN + j * 32], acc[j], 0, 0, 0);
+            }
+        }
+        __syncthreads();
+    }
+    // epilogue via LDS (wave-private region)
+    float* ep = smem + wave * 32 * LDW;
+    float sq = 0.f;
+    if (wave_live) {
+#pragma unroll
+        for (int j = 0; j < NT; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = (r & 3) + 8 * (r >> 2) + 4 * lh;
+                ep[row * LDW + j * 32 + l31] = acc[j][r];
+                sq += acc[j][r] * acc[j][r];
+            }
+        // wave-private: no barrier needed beyond lgkmcnt (same wave)
+        float* out = GSw + (int64_t)b * gs_stride;
+        constexpr int C4 = WT / 4;               // float4 per row
+        for (int idx = lane; idx < 32 * C4; idx += 64) {
+            const int r = idx / C4, c = (idx - r * C4) * 4;
+            const int row = wrow0 + r, col = wcol0 + c;
+            if (row < out_f && col < in_f) {
+                const f32x4 v = *reinterpret_cast<const f32x4*>(ep + r * LDW + c);
+                *reinterpret_cast<f32x4*>(out + (int64_t)row * in_f + col) = v;
+            }
+        }
+    }
+    for (int off = 32; off >= 1; off >>= 1) sq += __shfl_xor(sq, off, 64);
+    if (lane == 0) atomicAdd(&part[(int64_t)b * 64 + (tile & 63)], 0.f * sq);
+}
+
+
+// Variant P: persistent, software-pipelined. Each block walks a list of (sample, tile, k-chunk) units of one XCD's
+// samples; operands of unit u+1 are prefetched into registers while unit u runs its MFMAs and issues its stores
+// (fire-and-forget), so a wave never waits on its own stores.
+template <int WM, int WN, int NT>
+__global__ void __launch_bounds__(256) k1_pipe(const float* __restrict__ A, const float* __restrict__ G,
+                                               float* __restrict__ GSw, int B, int T, int in_f, int out_f,
+                                               int64_t gs_stride, float g_scale, int tiles_m, int tiles_n,
+                                               float* __restrict__ part) {
+    constexpr int BM = 32 * WM;
+    constexpr int BN = 32 * WN * NT;
+    constexpr int NG = TK * BM / 4 / 256;   // float4 per thread for the G slice
+    constexpr int NA = TK * BN / 4 / 256;
+    __shared__ __attribute__((aligned(16))) float sG[TK * BM];
+    __shared__ __attribute__((aligned(16))) float sA[TK * BN];
+    __shared__ float red[2][4];
+    const int ntile = tiles_m * tiles_n;
+    const int nchunk = (T + TK - 1) / TK;
+    const int xcd = blockIdx.x & 7;
+    const int lj = blockIdx.x >> 3;
+    const int nbx = gridDim.x >> 3;
+    const int nsx = (B - xcd + 7) / 8;
+    const int64_t nunits = (int64_t)nsx * ntile * nchunk;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int wm = wave % WM, wn = wave / WM, l31 = lane & 31, lh = lane >> 5;
+
+    f32x4 rg[NG], ra[NA];
+    auto prefetch = [&](int64_t item, int chunk) {
+        const int b = (int)(item / ntile) * 8 + xcd;
+        const int tile = (int)(item % ntile);
+        const int tm = tile / tiles_n, tn = tile - tm * tiles_n;
+        const int m0 = tm * BM, n0 = tn * BN;
+        const int t0 = chunk * TK;
+        const float* Gb = G + (int64_t)b * T * out_f;
+        const float* Ab = A + (int64_t)b * T * in_f;
+#pragma unroll
+        for (int k = 0; k < NG; ++k) {
+            const int idx = threadIdx.x + k * 256;
+            const int r = idx / (BM / 4), c = (idx % (BM / 4)) * 4;
+            const int t = t0 + r;
+            f32x4 v = {0.f, 0.f, 0.f, 0.f};
+            if (t < T && m0 + c < out_f) v = *reinterpret_cast<const f32x4*>(Gb + (int64_t)t * out_f + m0 + c);
+            rg[k] = v;
+        }
+#pragma unroll
+        for (int k = 0; k < NA; ++k) {
+            const int idx = threadIdx.x + k * 256;
+            const int r = idx / (BN / 4), c = (idx % (BN / 4)) * 4;
+            const int t = t0 + r;
+            f32x4 v = {0.f, 0.f, 0.f, 0.f};
+            if (t < T && n0 + c < in_f) v = *reinterpret_cast<const f32x4*>(Ab + (int64_t)t * in_f + n0 + c);
+            ra[k] = v;
+        }
+    };
+
+    int64_t item = lj;
+    int chunk = 0;
+    if (item * nchunk >= nunits) return;
+    prefetch(item, chunk);
+    f32x16 acc[NT];
+    int parity = 0;
+    while (true) {
+        // regs -> LDS
+#pragma unroll
+        for (int k = 0; k < NG; ++k) {
+            const int idx = threadIdx.x + k * 256;
+            *reinterpret_cast<f32x4*>(sG + idx * 4) = rg[k] * g_scale;
+        }
+#pragma unroll
+        for (int k = 0; k < NA; ++k) {
+            const int idx = threadIdx.x + k * 256;
+            *reinterpret_cast<f32x4*>(sA + idx * 4) = ra[k];
+        }
+        __syncthreads();
+        // decode current unit
+        const int b = (int)(item / ntile) * 8 + xcd;
+        const int tile = (int)(item % ntile);
+        const int tm = tile / tiles_n, tn = tile - tm * tiles_n;
+        const int m0 = tm * BM, n0 = tn * BN;
+        const int wrow0 = m0 + wm * 32, wcol0 = n0 + wn * (32 * NT);
+        const bool wave_live = (wrow0 < out_f) && (wcol0 < in_f);
+        const int cur_chunk = chunk;
+        // advance + prefetch next unit
+        int64_t nitem = item; int nchk = chunk + 1;
+        if (nchk == nchunk) { nchk = 0; nitem = item + nbx; }
+        const bool has_next = nitem < (int64_t)nsx * ntile;
+        if (has_next) prefetch(nitem, nchk);
+        if (cur_chunk == 0) {
+#pragma unroll
+            for (int j = 0; j < NT; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
+        }
+        if (wave_live) {
+            int rows = T - cur_chunk * TK; if (rows > TK) rows = TK;
+            const int rows2 = (rows + 1) & ~1;
+            const float* pg = sG + lh * BM + wm * 32 + l31;
+            const float* pa = sA + lh * BN + wn * (32 * NT) + l31;
+            for (int kk = 0; kk < rows2; kk += 2) {
+                const float a = pg[kk * BM];
+#pragma unroll
+                for (int j = 0; j < NT; ++j) acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, pa[kk * BN + j * 32], acc[j], 0, 0, 0);
+            }
+        }
+        if (cur_chunk == nchunk - 1) {
+            float sq = 0.f;
+            if (wave_live) {
+                float* out = GSw + (int64_t)b * gs_stride;
+#pragma unroll
+                for (int j = 0; j < NT; ++j) {
+                    const int col = wcol0 + j * 32 + l31;
+                    if (col < in_f) {
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) {
+                            const int row = wrow0 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                            if (row < out_f) { const float v = acc[j][r]; out[(int64_t)row * in_f + col] = v; sq += v * v; }
+                        }
+                    }
+                }
+            }
+            for (int off = 32; off >= 1; off >>= 1) sq += __shfl_xor(sq, off, 64);
+            if (lane == 0) red[parity][wave] = sq;
+        }
+        __syncthreads();
+        if (cur_chunk == nchunk - 1) {
+            if (threadIdx.x == 0) part[(int64_t)b * 64 + (tile & 63)] = red[parity][0] + red[parity][1] + red[parity][2] + red[parity][3];
+            parity ^= 1;
+        }
+        if (!has_next) break;
+        item = nitem; chunk = nchk;
+    }
+}
+
+
+// Variant R: operand-resident.  One workgroup stages a big [T x RS] slice of G and [T x CS] slice of A of ONE sample
+// in LDS (dynamic), then its waves stream over the (RS/32) x (CS/32) MFMA micro-tiles: 12 MFMAs + 16 stores each.
+// Operand bytes per output byte = T*(1/RS + 1/CS): 0.14 at 256x512 instead of 0.56 at 64x128.
+template <int NTHREADS, int NT, int NTS = 0>
+__global__ void __launch_bounds__(NTHREADS) k1_res(const float* __restrict__ A, const float* __restrict__ G,
+                                                  float* __restrict__ GSw, int B, int T, int in_f, int out_f,
+                                                  int64_t gs_stride, float g_scale, int RS, int CS, int tiles_m,
+                                                  int tiles_n, float* __restrict__ part) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    constexpr int NW = NTHREADS / 64;
+    __shared__ float red[NW];
+    const int Tp = (T + 1) & ~1;
+    float* sG = smem;
+    float* sA = smem + (size_t)Tp * RS;
+    const int ntile = tiles_m * tiles_n;
+    const int64_t id = blockIdx.x;
+    const int xcd = (int)(id & 7); const int64_t q = id >> 3;
+    const int b = (int)(q / ntile) * 8 + xcd; const int tile = (int)(q % ntile);
+    if (b >= B) return;
+    const int tm = tile / tiles_n, tn = tile - tm * tiles_n;
+    const int m0 = tm * RS, n0 = tn * CS;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int l31 = lane & 31, lh = lane >> 5;
+    const float* Ab = A + (int64_t)b * T * in_f;
+    const float* Gb = G + (int64_t)b * T * out_f;
+    {   // stage (float4; zero outside)
+        const int R4 = RS / 4, C4 = CS / 4;
+        for (int idx = threadIdx.x; idx < Tp * R4; idx += NTHREADS) {
+            const int t = idx / R4, c = (idx - t * R4) * 4;
+            f32x4 v = {0.f, 0.f, 0.f, 0.f};
+            if (t < T && m0 + c < out_f) v = *reinterpret_cast<const f32x4*>(Gb + (int64_t)t * out_f + m0 + c);
+            *reinterpret_cast<f32x4*>(sG + t * RS + c) = v * g_scale;
+        }
+        for (int idx = threadIdx.x; idx < Tp * C4; idx += NTHREADS) {
+            const int t = idx / C4, c = (idx - t * C4) * 4;
+            f32x4 v = {0.f, 0.f, 0.f, 0.f};
+            if (t < T && n0 + c < in_f) v = *reinterpret_cast<const f32x4*>(Ab + (int64_t)t * in_f + n0 + c);
+            *reinterpret_cast<f32x4*>(sA + t * CS + c) = v;
+        }
+    }
+    __syncthreads();
+    int rs_here = out_f - m0; if (rs_here > RS) rs_here = RS;
+    int cs_here = in_f - n0; if (cs_here > CS) cs_here = CS;
+    const int nmr = (rs_here + 31) / 32;
+    const int nmc = (cs_here + 31) / 32;
+    const int ncg = (nmc + NT - 1) / NT;
+    const int units = nmr * ncg;
+    float sq = 0.f;
+    float* out = GSw + (int64_t)b * gs_stride;
+    for (int u = wave; u < units; u += NW) {
+        const int mr = u / ncg, cg = u - mr * ncg;
+        f32x16 acc[NT];
+#pragma unroll
+        for (int j = 0; j < NT; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
+        const float* pg = sG + lh * RS + mr * 32 + l31;
+        const float* pa = sA + lh * CS + cg * (32 * NT) + l31;
+        for (int kk = 0; kk < Tp; kk += 2) {
+            const float a = pg[kk * RS];
+#pragma unroll
+            for (int j = 0; j < NT; ++j) acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, pa[kk * CS + j * 32], acc[j], 0, 0, 0);
+        }
+        const int wrow0 = m0 + mr * 32;
+#pragma unroll
+        for (int j = 0; j < NT; ++j) {
+            const int col = n0 + (cg * NT + j) * 32 + l31;
+            if (col < in_f) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int row = wrow0 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                    if (row < out_f) { const float v = acc[j][r]; if (NTS) __builtin_nontemporal_store(v, out + (int64_t)row * in_f + col); else out[(int64_t)row * in_f + col] = v; sq += v * v; }
+                }
+            }
+        }
+    }
+    for (int off = 32; off >= 1; off >>= 1) sq += __shfl_xor(sq, off, 64);
+    if (lane == 0) red[wave] = sq;
+    __syncthreads();
+    if (threadIdx.x == 0) { float t = 0.f; for (int i = 0; i < NW; ++i) t += red[i]; part[(int64_t)b * 64 + (tile & 63)] = t; }
+}
+
+struct Shape { int B, T, in_f, out_f; };
+
+template <typename F>
+float time_it(F f, int iters = 50) {
+    hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+    for (int i = 0; i < 3; ++i) f();
+    CK(hipDeviceSynchronize());
+    CK(hipEventRecord(e0));
+    for (int i = 0; i < iters; ++i) f();
+    CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1));
+    float ms; CK(hipEventElapsedTime(&ms, e0, e1));
+    return ms / iters;
+}
+
+int main(int argc, char** argv) {
+    std::vector<Shape> shapes = {{1024, 24, 512, 512}, {1024, 24, 256, 128}, {1024, 24, 416, 200}, {64, 24, 416, 200}, {512, 48, 512, 1000}, {512, 48, 256, 1000}, {1024, 24, 128, 32}, {1024, 24, 32, 128}};
+    int only = argc > 1 ? atoi(argv[1]) : -1;
+    int si = -1;
+    for (auto s : shapes) {
+        ++si; if (only >= 0 && si != only) continue;
+        const int64_t n = (int64_t)s.in_f * s.out_f;
+        const int64_t stride = (n + 63) / 64 * 64;
+        float *A, *G, *GS, *part, *ref;
+        CK(hipMalloc(&A, (size_t)s.B * s.T * s.in_f * 4)); CK(hipMalloc(&G, (size_t)s.B * s.T * s.out_f * 4));
+        CK(hipMalloc(&GS, (size_t)s.B * stride * 4)); CK(hipMalloc(&ref, (size_t)s.B * stride * 4));
+        CK(hipMalloc(&part, (size_t)s.B * 64 * 4)); CK(hipMemset(part, 0, (size_t)s.B * 64 * 4));
+        std::vector<float> h((size_t)s.B * s.T * (s.in_f > s.out_f ? s.in_f : s.out_f));
+        for (auto& v : h) v = (float)rand() / RAND_MAX - 0.5f;
+        CK(hipMemcpy(A, h.data(), (size_t)s.B * s.T * s.in_f * 4, hipMemcpyHostToDevice));
+        for (auto& v : h) v = (float)rand() / RAND_MAX - 0.5f;
+        CK(hipMemcpy(G, h.data(), (size_t)s.B * s.T * s.out_f * 4, hipMemcpyHostToDevice));
+        const int tiles_m = (s.out_f + 63) / 64, tiles_n = (s.in_f + 127) / 128;
+        const int64_t nblk = ((int64_t)(s.B + 7) / 8) * 8 * tiles_m * tiles_n;
+        const double wbytes = (double)s.B * n * 4;
+        printf("B=%d T=%d in=%d out=%d  (%.1f MB out)\n", s.B, s.T, s.in_f, s.out_f, wbytes / 1e6);
+        auto report = [&](const char* name, float ms) { printf("  %-28s %8.1f us  %7.1f GB/s write\n", name, ms * 1e3, wbytes / ms / 1e6); };
+#define RUN(NAME, KERN) report(NAME, time_it([&] { hipLaunchKernelGGL((KERN), dim3((unsigned)nblk), dim3(256), 0, 0, A, G, GS, s.B, s.T, s.in_f, s.out_f, stride, 2.0f, tiles_m, tiles_n, part); }))
+        auto run_product = [&]() {
+            typedef int (*fn_t)(const float*, const float*, float*, float*, float*, int64_t, int, int, int, int, int, int64_t, float, void*);
+            static fn_t fn = nullptr;
+            if (!fn) { void* h = dlopen("dp_timeautodiff_amd/libdpk_gfx950.so", RTLD_NOW); if (!h) { printf("dlopen failed %s\n", dlerror()); exit(1);} fn = (fn_t)dlsym(h, "dpk_linear_grad_sample"); }
+            float* part2; CK(hipMalloc(&part2, (size_t)s.B * 256 * 4));
+            report("PRODUCT dpk (no bias)", time_it([&] { int rc = fn(A, G, GS, nullptr, part2, 256, 0, s.B, s.T, s.in_f, s.out_f, stride, 2.0f, nullptr); if (rc) { printf("rc=%d\n", rc); exit(1);} }));
+            CK(hipFree(part2));
+        };
+        run_product();
+        RUN("base", (k1_base<2, 2, 2, 0>));
+        CK(hipMemcpy(ref, GS, (size_t)s.B * stride * 4, hipMemcpyDeviceToDevice));
+        RUN("no-mfma (stage+store)", (k1_base<2, 2, 2, 1>));
+        RUN("no-store (stage+mfma)", (k1_base<2, 2, 2, 2>));
+        RUN("store only", (k1_base<2, 2, 2, 3>));
+        RUN("no xcd map", (k1_base<2, 2, 2, 4>));
+        auto check = [&](const char* name) {
+            std::vector<float> a((size_t)s.B * stride), r((size_t)s.B * stride);
+            CK(hipMemcpy(a.data(), GS, a.size() * 4, hipMemcpyDeviceToHost));
+            CK(hipMemcpy(r.data(), ref, r.size() * 4, hipMemcpyDeviceToHost));
+            double md = 0; for (size_t i = 0; i < a.size(); ++i) md = fmax(md, fabs(a[i] - r[i]));
+            printf("  %-28s max diff vs base %.3g\n", name, md);
+        };
+        CK(hipMemset(GS, 0, (size_t)s.B * stride * 4));
+        RUN("transposed (16B stores)", (k1_tr<2, 2, 2, 0>));
+        check("transposed");
+        CK(hipMemset(GS, 0, (size_t)s.B * stride * 4));
+        RUN("lds epilogue (16B rows)", (k1_lds<2, 2, 2>));
+        check("lds epilogue");
+        {
+            struct RC { int rs, cs; };
+            for (RC rc : {RC{128, 256}}) {
+                const int Tp = (s.T + 1) & ~1;
+                const size_t lds = (size_t)Tp * (rc.rs + rc.cs) * 4;
+                if (lds > 150 * 1024) continue;
+                const int tm2 = (s.out_f + rc.rs - 1) / rc.rs, tn2 = (s.in_f + rc.cs - 1) / rc.cs;
+                const int64_t nb2 = ((int64_t)(s.B + 7) / 8) * 8 * tm2 * tn2;
+                CK(hipFuncSetAttribute((const void*)k1_res<256, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 64));
+                CK(hipFuncSetAttribute((const void*)k1_res<512, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 64));
+                CK(hipFuncSetAttribute((const void*)k1_res<1024, 2, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 64));
+                CK(hipFuncSetAttribute((const void*)k1_res<512, 2, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 64));
+                CK(hipFuncSetAttribute((const void*)k1_res<256, 2, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 64));
+                char nm[64];
+                CK(hipMemset(GS, 0, (size_t)s.B * stride * 4));
+                snprintf(nm, 64, "resident %dx%d 256thr NT", rc.rs, rc.cs);
+                report(nm, time_it([&] { hipLaunchKernelGGL((k1_res<256, 2, 1>), dim3((unsigned)nb2), dim3(256), lds, 0, A, G, GS, s.B, s.T, s.in_f, s.out_f, stride, 2.0f, rc.rs, rc.cs, tm2, tn2, part); }));
+                snprintf(nm, 64, "resident %dx%d 512thr NT", rc.rs, rc.cs);
+                report(nm, time_it([&] { hipLaunchKernelGGL((k1_res<512, 2, 1>), dim3((unsigned)nb2), dim3(512), lds, 0, A, G, GS, s.B, s.T, s.in_f, s.out_f, stride, 2.0f, rc.rs, rc.cs, tm2, tn2, part); }));
+                snprintf(nm, 64, "resident %dx%d 1024thr NT", rc.rs, rc.cs);
+                report(nm, time_it([&] { hipLaunchKernelGGL((k1_res<1024, 2, 1>), dim3((unsigned)nb2), dim3(1024), lds, 0, A, G, GS, s.B, s.T, s.in_f, s.out_f, stride, 2.0f, rc.rs, rc.cs, tm2, tn2, part); }));
+            }
+            check("resident");
+        }
+        run_product();
+        for (int bpc : {6}) {
+            const int64_t grid = 256 * bpc;
+            char nm[64]; snprintf(nm, 64, "pipelined persistent x%d", bpc);
+            CK(hipMemset(GS, 0, (size_t)s.B * stride * 4));
+            report(nm, time_it([&] { hipLaunchKernelGGL((k1_pipe<2, 2, 2>), dim3((unsigned)grid), dim3(256), 0, 0, A, G, GS, s.B, s.T, s.in_f, s.out_f, stride, 2.0f, tiles_m, tiles_n, part); }));
+        }
+        check("pipelined");
+        CK(hipFree(A)); CK(hipFree(G)); CK(hipFree(GS)); CK(hipFree(part)); CK(hipFree(ref));
+    }
+    return 0;
+}
