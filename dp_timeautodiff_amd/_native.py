@@ -36,10 +36,10 @@ EXPORTS = {
     "dpk_clip_reduce_workspace": (c_int64, [c_int, c_int64]),
     "dpk_clip_reduce": (c_int, [c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_int, c_int64, c_void_p,
                                 c_int64, c_void_p]),
-    "dpk_noise_scale": (c_int, [c_void_p, c_void_p, c_uint64, c_uint64, c_float, c_float, c_void_p, c_int64,
-                                c_void_p]),
+    "dpk_noise_scale": (c_int, [c_void_p, c_void_p, c_uint64, c_uint64, c_void_p, c_float, c_float, c_void_p,
+                                c_int64, c_void_p]),
     "dpk_clip_reduce_noise": (c_int, [c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_uint64, c_uint64,
-                                      c_float, c_float, c_void_p, c_void_p, c_int, c_int64, c_void_p, c_int64,
+                                      c_void_p, c_float, c_float, c_void_p, c_void_p, c_int, c_int64, c_void_p, c_int64,
                                       c_void_p]),
     "dpk_philox_normal": (c_int, [c_void_p, c_int64, c_uint64, c_uint64, c_float, c_void_p]),
 }
@@ -215,17 +215,18 @@ def clip_reduce(gs: FlatView, clip, summed_in, summed_out, B: int, workspace=Non
     _check(rc, "dpk_clip_reduce")
 
 
-def noise_scale(summed, noise, seed: int, offset: int, noise_std: float, inv_scale: float, grad, P: int):
+def noise_scale(summed, noise, seed: int, offset: int, noise_std: float, inv_scale: float, grad, P: int,
+                offset_dev=None):
     _req(grad, "grad")
     if grad.numel() < P or (summed is not None and summed.numel() < P) or (noise is not None and noise.numel() < P):
         raise DpkError("noise_scale: buffers shorter than P")
     rc = load().dpk_noise_scale(_ptr(summed), _ptr(noise), seed & (2**64 - 1), offset & (2**64 - 1),
-                                float(noise_std), float(inv_scale), _ptr(grad), P, _stream())
+                                _ptr(offset_dev), float(noise_std), float(inv_scale), _ptr(grad), P, _stream())
     _check(rc, "dpk_noise_scale")
 
 
 def clip_reduce_noise(gs: FlatView, clip, summed_in, noise, seed: int, offset: int, noise_std: float,
-                      inv_scale: float, summed_out, grad, B: int, workspace=None):
+                      inv_scale: float, summed_out, grad, B: int, workspace=None, offset_dev=None):
     _req(gs.base, "GS"); _req(clip, "clip"); _req(grad, "grad")
     P = gs.numel
     for t, n in ((summed_in, "summed_in"), (noise, "noise"), (summed_out, "summed_out"), (grad, "grad")):
@@ -235,8 +236,8 @@ def clip_reduce_noise(gs: FlatView, clip, summed_in, noise, seed: int, offset: i
         raise DpkError("clip_reduce_noise: buffers shorter than the batch")
     wp, wb = _ws_args(workspace)
     rc = load().dpk_clip_reduce_noise(gs.ptr, gs.stride, _ptr(clip), _ptr(summed_in), _ptr(noise),
-                                      seed & (2**64 - 1), offset & (2**64 - 1), float(noise_std), float(inv_scale),
-                                      _ptr(summed_out), _ptr(grad), B, P, wp, wb, _stream())
+                                      seed & (2**64 - 1), offset & (2**64 - 1), _ptr(offset_dev), float(noise_std),
+                                      float(inv_scale), _ptr(summed_out), _ptr(grad), B, P, wp, wb, _stream())
     _check(rc, "dpk_clip_reduce_noise")
 
 

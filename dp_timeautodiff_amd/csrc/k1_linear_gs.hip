@@ -58,13 +58,13 @@ __device__ __forceinline__ void stage_rows(float* __restrict__ s, const float* _
 // STREAM (T <= TK, one chunk): a wave computes a unit and stores it at once (16 live accumulator registers per
 // MFMA tile, stores of unit u overlap the MFMAs of unit u+1 of other waves); otherwise the accumulators of all
 // of a wave's units persist across the K-chunks.
-template <int NW, int RS, int CS, int NT, bool STREAM>
+template <int NW, int RS, int CS, int NT, bool STREAM, bool NTS>
 __global__ void __launch_bounds__(NW * 64) linear_gs_kernel(const float* __restrict__ A, const float* __restrict__ G,
                                                            float* __restrict__ GSw, float* __restrict__ GSb,
                                                            float* __restrict__ normsq_part, int64_t part_stride,
                                                            int slot0, int B, int T, int in_f, int out_f,
                                                            int64_t gs_stride, float g_scale, int tiles_m,
-                                                           int tiles_n, int vecA, int vecG, int nt_store) {
+                                                           int tiles_n, int vecA, int vecG) {
     constexpr int NTHR = NW * 64;
     constexpr int NCG = CS / (32 * NT);        // column groups per tile
     constexpr int UNITS = (RS / 32) * NCG;
@@ -116,8 +116,8 @@ __global__ void __launch_bounds__(NW * 64) linear_gs_kernel(const float* __restr
                     if (row < out_f) {
                         const float v = acc[j][r];
                         float* p = out + (int64_t)row * in_f + col;
-                        if (nt_store)
-                            __builtin_nontemporal_store(v, p);
+                        if constexpr (NTS)
+                            __builtin_nontemporal_store(v, p);  // whole 128-B lines, read back once much later
                         else
                             *p = v;
                         sq += v * v;
@@ -250,17 +250,17 @@ extern "C" int dpk_linear_grad_sample(const float* A, const float* G, float* GSw
     dim3 grid((unsigned)nblk);
     const bool stream_mode = T <= TK;
     const int lds_rows = stream_mode ? ((T + 1) & ~1) : TK;
+#define DPK_K1_GO(NW, RS, CS, NT, ST, NTS)                                                                       \
+    hipLaunchKernelGGL((linear_gs_kernel<NW, RS, CS, NT, ST, NTS>), grid, dim3(NW * 64), lds, s, A, G, GSw, GSb,  \
+                       normsq_part, part_stride, slot0, B, T, in_f, out_f, gs_stride, g_scale, tiles_m, tiles_n,  \
+                       vecA, vecG)
 #define DPK_K1_LAUNCH(NW, RS, CS, NT)                                                                          \
     do {                                                                                                       \
         const size_t lds = ((size_t)lds_rows * (RS + CS) + NW) * sizeof(float);                                \
-        if (stream_mode)                                                                                       \
-            hipLaunchKernelGGL((linear_gs_kernel<NW, RS, CS, NT, true>), grid, dim3(NW * 64), lds, s, A, G, GSw, \
-                               GSb, normsq_part, part_stride, slot0, B, T, in_f, out_f, gs_stride, g_scale,      \
-                               tiles_m, tiles_n, vecA, vecG, nt_store);                                          \
-        else                                                                                                   \
-            hipLaunchKernelGGL((linear_gs_kernel<NW, RS, CS, NT, false>), grid, dim3(NW * 64), lds, s, A, G,     \
-                               GSw, GSb, normsq_part, part_stride, slot0, B, T, in_f, out_f, gs_stride, g_scale, \
-                               tiles_m, tiles_n, vecA, vecG, nt_store);                                          \
+        if (stream_mode && nt_store) DPK_K1_GO(NW, RS, CS, NT, true, true);                                    \
+        else if (stream_mode) DPK_K1_GO(NW, RS, CS, NT, true, false);                                          \
+        else if (nt_store) DPK_K1_GO(NW, RS, CS, NT, false, true);                                             \
+        else DPK_K1_GO(NW, RS, CS, NT, false, false);                                                          \
     } while (0)
     switch (p.id) {
         case 0: DPK_K1_LAUNCH(8, 128, 256, 2); break;
@@ -270,5 +270,6 @@ extern "C" int dpk_linear_grad_sample(const float* A, const float* G, float* GSw
         default: DPK_K1_LAUNCH(4, 128, 32, 1); break;
     }
 #undef DPK_K1_LAUNCH
+#undef DPK_K1_GO
     return dpk_launch_status();
 }

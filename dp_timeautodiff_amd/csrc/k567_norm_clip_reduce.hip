@@ -60,13 +60,14 @@ __global__ void __launch_bounds__(256) clip_factor_kernel(const float* __restric
 }
 
 __device__ __forceinline__ f32x4 noise4(const float* __restrict__ noise, int64_t j, uint32_t k0, uint32_t k1,
-                                        uint64_t offset, float noise_std) {
+                                        uint64_t offset, const uint64_t* __restrict__ offset_dev,
+                                        float noise_std) {
     f32x4 z = {0.f, 0.f, 0.f, 0.f};
     if (noise) {
         z = *reinterpret_cast<const f32x4*>(noise + j);
     } else if (noise_std != 0.f) {
         float n[4];
-        philox_normal4(offset + (uint64_t)(j >> 2), k0, k1, n);
+        philox_normal4(offset + (offset_dev ? *offset_dev : 0ull) + (uint64_t)(j >> 2), k0, k1, n);
         z = f32x4{n[0], n[1], n[2], n[3]} * noise_std;
     }
     return z;
@@ -79,7 +80,8 @@ __global__ void __launch_bounds__(256) clip_reduce_kernel(const float* __restric
                                                           const float* __restrict__ summed_in,
                                                           float* __restrict__ out0, float* __restrict__ grad,
                                                           const float* __restrict__ noise, uint32_t k0, uint32_t k1,
-                                                          uint64_t offset, float noise_std, float inv_scale, int B,
+                                                          uint64_t offset, const uint64_t* __restrict__ offset_dev, float noise_std,
+                                                          float inv_scale, int B,
                                                           int64_t P, int b_per_split) {
     const int64_t j = ((int64_t)blockIdx.x * 256 + threadIdx.x) * 4;
     if (j >= P) return;
@@ -108,7 +110,7 @@ __global__ void __launch_bounds__(256) clip_reduce_kernel(const float* __restric
         if (summed_in) acc += *reinterpret_cast<const f32x4*>(summed_in + j);
         if (out0) *reinterpret_cast<f32x4*>(out0 + j) = acc;
         if (MODE == 2) {
-            const f32x4 z = noise4(noise, j, k0, k1, offset, noise_std);
+            const f32x4 z = noise4(noise, j, k0, k1, offset, offset_dev, noise_std);
             *reinterpret_cast<f32x4*>(grad + j) = (acc + z) * inv_scale;
         }
     }
@@ -120,7 +122,8 @@ __global__ void __launch_bounds__(256) finalize_kernel(const float* __restrict__
                                                        const float* __restrict__ summed_in,
                                                        float* __restrict__ summed_out, float* __restrict__ grad,
                                                        const float* __restrict__ noise, uint32_t k0, uint32_t k1,
-                                                       uint64_t offset, float noise_std, float inv_scale, int64_t P) {
+                                                       uint64_t offset, const uint64_t* __restrict__ offset_dev, float noise_std,
+                                                       float inv_scale, int64_t P) {
     const int64_t j = ((int64_t)blockIdx.x * 256 + threadIdx.x) * 4;
     if (j >= P) return;
     f32x4 acc = {0.f, 0.f, 0.f, 0.f};
@@ -128,7 +131,7 @@ __global__ void __launch_bounds__(256) finalize_kernel(const float* __restrict__
     if (summed_in) acc += *reinterpret_cast<const f32x4*>(summed_in + j);
     if (summed_out) *reinterpret_cast<f32x4*>(summed_out + j) = acc;
     if (FINAL) {
-        const f32x4 z = noise4(noise, j, k0, k1, offset, noise_std);
+        const f32x4 z = noise4(noise, j, k0, k1, offset, offset_dev, noise_std);
         *reinterpret_cast<f32x4*>(grad + j) = (acc + z) * inv_scale;
     }
 }
@@ -136,17 +139,18 @@ __global__ void __launch_bounds__(256) finalize_kernel(const float* __restrict__
 // grad = (summed + z) * inv_scale ; scalar tail handled so P need not be a multiple of 4
 __global__ void __launch_bounds__(256) noise_scale_kernel(const float* __restrict__ summed,
                                                           const float* __restrict__ noise, uint32_t k0, uint32_t k1,
-                                                          uint64_t offset, float noise_std, float inv_scale,
-                                                          float* __restrict__ grad, int64_t P, int vec) {
+                                                          uint64_t offset, const uint64_t* __restrict__ offset_dev, float noise_std,
+                                                          float inv_scale, float* __restrict__ grad, int64_t P, int vec) {
     const int64_t j = ((int64_t)blockIdx.x * 256 + threadIdx.x) * 4;
     if (j >= P) return;
     if (vec && j + 4 <= P) {
         const f32x4 s = summed ? *reinterpret_cast<const f32x4*>(summed + j) : f32x4{0.f, 0.f, 0.f, 0.f};
-        const f32x4 z = noise4(noise, j, k0, k1, offset, noise_std);
+        const f32x4 z = noise4(noise, j, k0, k1, offset, offset_dev, noise_std);
         *reinterpret_cast<f32x4*>(grad + j) = (s + z) * inv_scale;
     } else {
         float n[4] = {0.f, 0.f, 0.f, 0.f};
-        if (!noise && noise_std != 0.f) philox_normal4(offset + (uint64_t)(j >> 2), k0, k1, n);
+        if (!noise && noise_std != 0.f)
+            philox_normal4(offset + (offset_dev ? *offset_dev : 0ull) + (uint64_t)(j >> 2), k0, k1, n);
         for (int k = 0; k < 4 && j + k < P; ++k) {
             const float z = noise ? noise[j + k] : n[k] * noise_std;
             grad[j + k] = ((summed ? summed[j + k] : 0.f) + z) * inv_scale;
@@ -166,8 +170,8 @@ inline int pick_nsplit(int B, int64_t P) {
 }
 
 int clip_reduce_impl(const float* GS, int64_t gs_stride, const float* clip, const float* summed_in,
-                     const float* noise, uint64_t seed, uint64_t offset, float noise_std, float inv_scale,
-                     float* summed_out, float* grad, bool final_, int B, int64_t P, void* workspace,
+                     const float* noise, uint64_t seed, uint64_t offset, const uint64_t* offset_dev, float noise_std,
+                     float inv_scale, float* summed_out, float* grad, bool final_, int B, int64_t P, void* workspace,
                      int64_t workspace_bytes, void* stream) {
     if (!GS || !clip) return DPK_EINVAL;
     if (final_ ? !grad : !summed_out) return DPK_EINVAL;
@@ -185,10 +189,10 @@ int clip_reduce_impl(const float* GS, int64_t gs_stride, const float* clip, cons
         dim3 grid((unsigned)blocks_x, 1);
         if (final_)
             hipLaunchKernelGGL((clip_reduce_kernel<2>), grid, dim3(256), 0, s, GS, gs_stride, clip, summed_in,
-                               summed_out, grad, noise, k0, k1, offset, noise_std, inv_scale, B, P, B > 0 ? B : 1);
+                               summed_out, grad, noise, k0, k1, offset, offset_dev, noise_std, inv_scale, B, P, B > 0 ? B : 1);
         else
             hipLaunchKernelGGL((clip_reduce_kernel<1>), grid, dim3(256), 0, s, GS, gs_stride, clip, summed_in,
-                               summed_out, grad, noise, k0, k1, offset, noise_std, inv_scale, B, P, B > 0 ? B : 1);
+                               summed_out, grad, noise, k0, k1, offset, offset_dev, noise_std, inv_scale, B, P, B > 0 ? B : 1);
         return dpk_launch_status();
     }
     const int64_t need = (int64_t)nsplit * P * 4;
@@ -196,18 +200,18 @@ int clip_reduce_impl(const float* GS, int64_t gs_stride, const float* clip, cons
     const int bps = (B + nsplit - 1) / nsplit;
     dim3 grid((unsigned)blocks_x, (unsigned)nsplit);
     hipLaunchKernelGGL((clip_reduce_kernel<0>), grid, dim3(256), 0, s, GS, gs_stride, clip, (const float*)nullptr,
-                       (float*)workspace, (float*)nullptr, (const float*)nullptr, k0, k1, offset, noise_std,
+                       (float*)workspace, (float*)nullptr, (const float*)nullptr, k0, k1, offset, offset_dev, noise_std,
                        inv_scale, B, P, bps);
     int rc = dpk_launch_status();
     if (rc) return rc;
     if (final_)
         hipLaunchKernelGGL((finalize_kernel<true>), dim3((unsigned)blocks_x), dim3(256), 0, s,
                            (const float*)workspace, nsplit, summed_in, summed_out, grad, noise, k0, k1, offset,
-                           noise_std, inv_scale, P);
+                           offset_dev, noise_std, inv_scale, P);
     else
         hipLaunchKernelGGL((finalize_kernel<false>), dim3((unsigned)blocks_x), dim3(256), 0, s,
                            (const float*)workspace, nsplit, summed_in, summed_out, grad, noise, k0, k1, offset,
-                           noise_std, inv_scale, P);
+                           offset_dev, noise_std, inv_scale, P);
     return dpk_launch_status();
 }
 
@@ -250,31 +254,32 @@ extern "C" int64_t dpk_clip_reduce_workspace(int B, int64_t P) {
 extern "C" int dpk_clip_reduce(const float* GS, int64_t gs_stride, const float* clip, const float* summed_in,
                                float* summed_out, int B, int64_t P, void* workspace, int64_t workspace_bytes,
                                void* stream) {
-    return clip_reduce_impl(GS, gs_stride, clip, summed_in, nullptr, 0, 0, 0.f, 1.f, summed_out, nullptr, false, B,
+    return clip_reduce_impl(GS, gs_stride, clip, summed_in, nullptr, 0, 0, nullptr, 0.f, 1.f, summed_out, nullptr, false, B,
                             P, workspace, workspace_bytes, stream);
 }
 
 extern "C" int dpk_clip_reduce_noise(const float* GS, int64_t gs_stride, const float* clip, const float* summed_in,
-                                     const float* noise, uint64_t seed, uint64_t offset, float noise_std,
-                                     float inv_scale, float* summed_out, float* grad, int B, int64_t P,
-                                     void* workspace, int64_t workspace_bytes, void* stream) {
-    return clip_reduce_impl(GS, gs_stride, clip, summed_in, noise, seed, offset, noise_std, inv_scale, summed_out,
+                                     const float* noise, uint64_t seed, uint64_t offset,
+                                     const uint64_t* offset_dev, float noise_std, float inv_scale,
+                                     float* summed_out, float* grad, int B, int64_t P, void* workspace,
+                                     int64_t workspace_bytes, void* stream) {
+    return clip_reduce_impl(GS, gs_stride, clip, summed_in, noise, seed, offset, offset_dev, noise_std, inv_scale, summed_out,
                             grad, true, B, P, workspace, workspace_bytes, stream);
 }
 
 extern "C" int dpk_noise_scale(const float* summed, const float* noise, uint64_t seed, uint64_t offset,
-                               float noise_std, float inv_scale, float* grad, int64_t P, void* stream) {
+                               const uint64_t* offset_dev, float noise_std, float inv_scale, float* grad, int64_t P, void* stream) {
     if (!grad || P <= 0) return DPK_EINVAL;
     const int64_t blocks_x = ((P + 3) / 4 + 255) / 256;
     if (blocks_x > 0x7fffffffLL) return DPK_ERANGE;
     const int vec = dpk_aligned16(grad) && (!summed || dpk_aligned16(summed)) && (!noise || dpk_aligned16(noise));
     hipLaunchKernelGGL(noise_scale_kernel, dim3((unsigned)blocks_x), dim3(256), 0, (hipStream_t)stream, summed,
-                       noise, (uint32_t)seed, (uint32_t)(seed >> 32), offset, noise_std, inv_scale, grad, P, vec);
+                       noise, (uint32_t)seed, (uint32_t)(seed >> 32), offset, offset_dev, noise_std, inv_scale, grad, P, vec);
     return dpk_launch_status();
 }
 
 extern "C" int dpk_philox_normal(float* out, int64_t n, uint64_t seed, uint64_t offset, float std, void* stream) {
-    return dpk_noise_scale(nullptr, nullptr, seed, offset, std, 1.0f, out, n, stream);
+    return dpk_noise_scale(nullptr, nullptr, seed, offset, nullptr, std, 1.0f, out, n, stream);
 }
 
 extern "C" int dpk_version(void) { return DPK_VERSION; }

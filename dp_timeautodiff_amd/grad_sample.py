@@ -134,6 +134,8 @@ class _Layer:
 
     def __init__(self, name: str, module: nn.Module, kind: str, slot0: int, nslots: int):
         self.name, self.module, self.kind, self.slot0, self.nslots = name, module, kind, slot0, nslots
+        self.params: List[nn.Parameter] = [p for p in module.parameters(recurse=False)]
+        self.frozen_for_autograd = False
         self.acts: List[torch.Tensor] = []
         self.pairs: List[Tuple[torch.Tensor, torch.Tensor]] = []
         self.counter = 0
@@ -155,8 +157,13 @@ class GradSampleModule(nn.Module):
     """Wraps `m`; after backward every trainable parameter has `.grad_sample` ([B, *shape] view)."""
 
     def __init__(self, m: nn.Module, *, batch_first: bool = True, loss_reduction: str = "mean",
-                 strict: bool = True, force_functorch: bool = False):
+                 strict: bool = True, force_functorch: bool = False, skip_autograd_param_grads: bool = True):
         super().__init__()
+        # Autograd's own (summed) parameter gradients are never used by DP-SGD: DPOptimizer overwrites p.grad.
+        # While a sampled layer runs forward on an input that already requires grad, its parameters are
+        # switched to requires_grad=False, so backward computes only dL/dx (which the hooks need) and skips the
+        # dW GEMM, the bias reduction and the .grad accumulation of every one of the T calls.
+        self.skip_autograd_param_grads = skip_autograd_param_grads
         if loss_reduction not in ("mean", "sum"):
             raise ValueError(f"loss_reduction = {loss_reduction}. Only 'sum' and 'mean' losses are supported")
         self._module = m
@@ -204,6 +211,7 @@ class GradSampleModule(nn.Module):
             self._layers.append(layer)
             for p in own:
                 covered.add(id(p))
+            self._handles.append(sub.register_forward_pre_hook(self._make_pre(layer)))
             self._handles.append(sub.register_forward_hook(self._make_fwd(layer)))
             self._handles.append(sub.register_full_backward_hook(self._make_bwd(layer)))
         for n_, p in params:
@@ -291,15 +299,29 @@ class GradSampleModule(nn.Module):
         return errors
 
     # ---- hooks ----------------------------------------------------------------------------------------
+    def _make_pre(self, layer: _Layer):
+        def hook(module, inputs):
+            if (self.skip_autograd_param_grads and self.hooks_enabled and module.training
+                    and torch.is_grad_enabled() and layer.kind != "embedding"
+                    and isinstance(inputs[0], torch.Tensor) and inputs[0].requires_grad):
+                for p in layer.params:
+                    p.requires_grad_(False)
+                layer.frozen_for_autograd = True
+
+        return hook
+
     def _make_fwd(self, layer: _Layer):
         def hook(module, inputs, output):
+            if layer.frozen_for_autograd:
+                for p in layer.params:
+                    p.requires_grad_(True)
+                layer.frozen_for_autograd = False
             if not self.hooks_enabled or not module.training or not torch.is_grad_enabled():
                 return
             layer.acts.append(inputs[0].detach())
             layer.counter += 1
-            for p in module.parameters(recurse=False):
-                if p.requires_grad:
-                    p._forward_counter += 1
+            for p in layer.params:
+                p._forward_counter += 1
 
         return hook
 
@@ -313,9 +335,8 @@ class GradSampleModule(nn.Module):
             a = layer.acts.pop()  # LIFO: backward visits calls in reverse
             layer.pairs.append((a, g.detach()))
             layer.counter -= 1
-            for p in module.parameters(recurse=False):
-                if p.requires_grad:
-                    p._forward_counter -= 1
+            for p in layer.params:
+                p._forward_counter -= 1
             if layer.counter == 0:
                 self._materialise(layer)
 

@@ -1,0 +1,104 @@
+"""GraphedDPStep: one whole DP-SGD training step captured into a hipGraph.
+
+The reference's step (Model_Code/timeautoencoder.py:732-751: zero_grad, forward, loss, backward, step) is
+launch-bound on any GPU: the Linear-cell GRU's T-step Python loop (:84-94) alone issues ~1000 small kernels per
+step.  On MI355X the idiomatic answer is not a tracing compiler but a HIP graph: the eager step — autograd
+kernels, the hooks' stacking copies, the dpk per-sample-gradient launches (plain hipLaunchKernel calls on the
+capturing stream), K6/K7 and a capturable Adam — is captured once and replayed with one host call.
+
+Constraints (checked or documented): fixed physical batch size and static input tensors (copy each batch into
+them); the arena must have reached its capacity before capture (the warm-up steps do that); the Philox noise
+offset lives in device memory and is advanced by a node of the graph, so every replay draws fresh noise; the
+accountant's step hook is host code and is called once per replay.
+"""
+from __future__ import annotations
+
+from typing import Callable, Optional
+
+import torch
+
+from .grad_sample import GradSampleModule
+from .optimizer import DistributedDPOptimizer, DPOptimizer
+
+
+def _make_capturable(optimizer: torch.optim.Optimizer):
+    """Adam/AdamW-family optimizers need capturable=True (device-side step counters) under graph capture."""
+    for group in optimizer.param_groups:
+        if "capturable" in group and not group["capturable"]:
+            group["capturable"] = True
+            if group.get("fused"):
+                continue
+    for p, st in optimizer.state.items():
+        if isinstance(st, dict) and "step" in st and torch.is_tensor(st["step"]) and not st["step"].is_cuda:
+            st["step"] = st["step"].to(p.device, dtype=torch.float32)
+
+
+class GraphedDPStep:
+    def __init__(self, module: GradSampleModule, optimizer: DPOptimizer, loss_fn: Callable[[], torch.Tensor],
+                 warmup: int = 3):
+        """`loss_fn()` runs forward + loss on STATIC device tensors and returns the scalar loss."""
+        if not isinstance(module, GradSampleModule) or not isinstance(optimizer, DPOptimizer):
+            raise TypeError("GraphedDPStep needs the GradSampleModule and DPOptimizer returned by PrivacyEngine")
+        self.module, self.optimizer, self.loss_fn = module, optimizer, loss_fn
+        self.graph: Optional[torch.cuda.CUDAGraph] = None
+        self.static_loss: Optional[torch.Tensor] = None
+        self.warmup = warmup
+        self.replays = 0
+        # data-parallel: only the communication-free part is captured; the flat all-reduce, the shared-noise
+        # kernel and the wrapped optimizer run eagerly after each replay (4-15 launches)
+        self.distributed = isinstance(optimizer, DistributedDPOptimizer)
+
+    def _eager_step(self):
+        opt = self.optimizer
+        opt.zero_grad(set_to_none=True)
+        loss = self.loss_fn()
+        loss.backward()
+        opt.step()
+        return loss.detach()
+
+    def _local_part(self):
+        opt = self.optimizer
+        opt.zero_grad(set_to_none=True)
+        loss = self.loss_fn()
+        loss.backward()
+        opt.local_step()
+        return loss.detach()
+
+    def capture(self):
+        opt = self.optimizer
+        if opt._step_skip_queue:
+            raise RuntimeError("capture a step outside BatchMemoryManager (pending skip-step signals)")
+        if opt.generator is not None:
+            raise RuntimeError("a torch noise generator cannot be captured; use the Philox stream (default)")
+        if not self.distributed:
+            _make_capturable(opt.original_optimizer)
+            opt.enable_device_noise_offset()
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            for _ in range(self.warmup):  # real training steps: allocate arena / optimizer state, count in accountant
+                self._eager_step()
+        torch.cuda.current_stream().wait_stream(side)
+        torch.cuda.synchronize()
+        capacity = self.module.arena.capacity
+        hook, opt.step_hook = opt.step_hook, None  # host-side accounting happens per replay, not at capture
+        self.graph = torch.cuda.CUDAGraph()
+        try:
+            with torch.cuda.graph(self.graph):
+                self.static_loss = self._local_part() if self.distributed else self._eager_step()
+        finally:
+            opt.step_hook = hook
+        if self.module.arena.capacity != capacity:
+            raise RuntimeError("the per-sample-gradient arena grew during capture; warm up with the capture batch size")
+        return self
+
+    def __call__(self) -> torch.Tensor:
+        if self.graph is None:
+            self.capture()
+        self.graph.replay()
+        self.replays += 1
+        if self.distributed:
+            self.optimizer.finish_step()  # calls the accountant hook itself
+        elif self.optimizer.step_hook:
+            self.optimizer.step_hook(self.optimizer)
+        return self.static_loss

@@ -58,6 +58,7 @@ class DPOptimizer(Optimizer):
         self._is_last_step_skipped = False
         self.noise_seed = _generate_seed() if noise_seed is None else int(noise_seed)
         self._noise_offset = 0  # Philox blocks consumed so far (advances by P/4 per real step)
+        self._noise_offset_dev: Optional[torch.Tensor] = None  # device-side offset (hipGraph-captured steps)
         self._injected_noise: Optional[torch.Tensor] = None
         self._arena = None
         self._gsm = None
@@ -119,6 +120,13 @@ class DPOptimizer(Optimizer):
     def attach_step_hook(self, fn: Callable[["DPOptimizer"], None]):
         self.step_hook = fn
 
+    def enable_device_noise_offset(self):
+        """Keep the Philox offset in a device word that the step itself advances (K7 reads it through
+        `offset_dev`), so a step captured into a hipGraph draws fresh noise on every replay."""
+        if self._noise_offset_dev is None:
+            self._noise_offset_dev = torch.tensor([self._noise_offset], dtype=torch.int64, device=self.arena.device)
+            self._noise_offset = 0
+
     def inject_noise(self, flat_noise: torch.Tensor):
         """Parity/testing: use this [P_arena] tensor (already scaled by sigma*C) for the next real step."""
         self._injected_noise = flat_noise
@@ -174,14 +182,21 @@ class DPOptimizer(Optimizer):
             z = torch.normal(mean=0.0, std=std, size=(arena.P,), device=arena.device, generator=self.generator)
             return z, 0, 0, 0.0
         off = self._noise_offset
-        self._noise_offset += arena.P // 4
+        if self._noise_offset_dev is None:
+            self._noise_offset += arena.P // 4
         return None, self.noise_seed, off, std
+
+    def _advance_device_offset(self, arena, used_philox: bool):
+        if used_philox and self._noise_offset_dev is not None:
+            self._noise_offset_dev.add_(arena.P // 4)  # a graph node when captured
 
     def add_noise(self):
         """K7b with unit scale: p.grad = p.summed_grad + N(0, (sigma*C)^2)."""
         arena = self.arena
         noise, seed, off, std = self._noise_args(arena)
-        _native.noise_scale(arena.summed, noise, seed, off, std, 1.0, arena.grad, arena.P)
+        _native.noise_scale(arena.summed, noise, seed, off, std, 1.0, arena.grad, arena.P,
+                            offset_dev=self._noise_offset_dev)
+        self._advance_device_offset(arena, noise is None and std != 0)
         self._publish_grad(arena)
 
     def scale_grad(self):
@@ -199,7 +214,9 @@ class DPOptimizer(Optimizer):
         ws = arena.ensure_workspace(B)
         _native.clip_reduce_noise(_native.FlatView(arena.buf, 0, arena.P), arena.clip,
                                   arena.summed if arena.summed_valid else None, noise, seed, off, std,
-                                  self._inv_scale(), arena.summed, arena.grad, B, ws)
+                                  self._inv_scale(), arena.summed, arena.grad, B, ws,
+                                  offset_dev=self._noise_offset_dev)
+        self._advance_device_offset(arena, noise is None and std != 0)
         arena.summed_valid = True
 
     def pre_step(self, closure: Optional[Callable[[], float]] = None) -> Optional[float]:
@@ -307,13 +324,43 @@ class DistributedDPOptimizer(DPOptimizer):
         return s / self.world_size if self.loss_reduction == "mean" else s
 
     def _reduce_noise_scale(self, arena, B):
+        self._local_reduce(arena, B)
+        self._exchange_noise_scale(arena)
+
+    def _local_reduce(self, arena, B):
         ws = arena.ensure_workspace(B)
         _native.clip_reduce(_native.FlatView(arena.buf, 0, arena.P), arena.clip,
                             arena.summed if arena.summed_valid else None, arena.summed, B, ws)
         arena.summed_valid = True
+
+    def _exchange_noise_scale(self, arena):
         self._dist.all_reduce(arena.summed, op=self._dist.ReduceOp.SUM, group=self.process_group)
         noise, seed, off, std = self._noise_args(arena)
-        _native.noise_scale(arena.summed, noise, seed, off, std, self._inv_scale(), arena.grad, arena.P)
+        _native.noise_scale(arena.summed, noise, seed, off, std, self._inv_scale(), arena.grad, arena.P,
+                            offset_dev=self._noise_offset_dev)
+        self._advance_device_offset(arena, noise is None and std != 0)
+
+    # -- two-phase form used by GraphedDPStep: the local phase is captured, the exchange stays eager ------------
+    def local_step(self):
+        """zero-communication part of a real step: K6 + K7a on this rank's examples."""
+        arena, B = self._prepare()
+        arena.ensure(max(B, 1))
+        if self._check_skip_next_step():
+            raise RuntimeError("local_step() is for real steps only (skip-step signal pending)")
+        self._clip_factors(arena, B)
+        self._local_reduce(arena, B)
+        arena.consumed = True
+
+    def finish_step(self):
+        """all-reduce of the flat clipped sum, shared-Philox noise + scale, accountant hook, wrapped optimizer."""
+        arena = self.arena
+        self._exchange_noise_scale(arena)
+        self._publish_summed(arena)
+        self._publish_grad(arena)
+        if self.step_hook:
+            self.step_hook(self)
+        self._is_last_step_skipped = False
+        return self.original_optimizer.step()
 
     def add_noise(self):
         raise NotImplementedError("use step(): the distributed path all-reduces between sum and noise")

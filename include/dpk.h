@@ -124,15 +124,17 @@ int dpk_clip_reduce(const float* GS, int64_t gs_stride, const float* clip, const
  * already scaled by std — the parity path), else noise_std * Philox4x32-10 normal #j of the stream
  * (seed, offset): element j uses Philox block (offset + j/4), lane j%4 — every rank of a data-parallel
  * job draws the same z from the same (seed, offset).  noise_std == 0 and noise == NULL -> z = 0.
+ * offset_dev (nullable) points at a DEVICE uint64 added to `offset` when the kernel runs: a step captured into
+ * a hipGraph keeps drawing fresh noise on every replay (the host, or a node of the graph, advances the word).
  */
 int dpk_noise_scale(const float* summed, const float* noise, uint64_t seed, uint64_t offset,
-                    float noise_std, float inv_scale, float* grad, int64_t P, void* stream);
+                    const uint64_t* offset_dev, float noise_std, float inv_scale, float* grad, int64_t P, void* stream);
 
 /* K7 fused = K7a followed by K7b without the intermediate P-sized round trip (single-GPU path).
  * summed_out (nullable) additionally receives the un-noised clipped sum. */
 int dpk_clip_reduce_noise(const float* GS, int64_t gs_stride, const float* clip, const float* summed_in,
-                          const float* noise, uint64_t seed, uint64_t offset, float noise_std,
-                          float inv_scale, float* summed_out, float* grad, int B, int64_t P,
+                          const float* noise, uint64_t seed, uint64_t offset, const uint64_t* offset_dev,
+                          float noise_std, float inv_scale, float* summed_out, float* grad, int B, int64_t P,
                           void* workspace, int64_t workspace_bytes, void* stream);
 
 /* Philox normal stream on its own (tests; also lets host code pre-draw the shared noise). */

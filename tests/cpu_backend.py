@@ -84,19 +84,21 @@ def _noise(noise, seed, offset, std, P):
     return torch.from_numpy(O.philox_normal(P, seed, offset, std))
 
 
-def noise_scale(summed, noise, seed, offset, noise_std, inv_scale, grad, P):
+def noise_scale(summed, noise, seed, offset, noise_std, inv_scale, grad, P, offset_dev=None):
+    if offset_dev is not None:
+        offset = offset + int(offset_dev.item())
     s = summed[:P] if summed is not None else torch.zeros(P)
     grad[:P] = (s + _noise(noise, seed, offset, noise_std, P)) * inv_scale
 
 
 def clip_reduce_noise(gs, clip, summed_in, noise, seed, offset, noise_std, inv_scale, summed_out, grad, B,
-                      workspace=None):
+                      workspace=None, offset_dev=None):
     P = gs.numel
     tmp = torch.zeros(P)
     clip_reduce(gs, clip, summed_in, tmp, B)
     if summed_out is not None:
         summed_out[:P] = tmp
-    noise_scale(tmp, noise, seed, offset, noise_std, inv_scale, grad, P)
+    noise_scale(tmp, noise, seed, offset, noise_std, inv_scale, grad, P, offset_dev)
 
 
 def philox_normal(out, seed, offset, std):
