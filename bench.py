@@ -261,9 +261,9 @@ def hot_path(native, gsm, opt, wl, chunks, steps):
     orig = {n: getattr(native, n) for n in ("linear_grad_sample", "embedding_grad_sample", "layernorm_grad_sample")}
 
     def cap(name):
-        def f(*a):
-            captured.append((name, a))
-            return orig[name](*a)
+        def f(*a, **k):
+            captured.append((name, a, k))
+            return orig[name](*a, **k)
         return f
 
     for n in orig:
@@ -281,8 +281,8 @@ def hot_path(native, gsm, opt, wl, chunks, steps):
     full = native.FlatView(arena.buf, 0, arena.P)
 
     def replay():
-        for name, a in captured:
-            orig[name](*a)
+        for name, a, k in captured:
+            orig[name](*a, **k)
         native.clip_factors(arena.part, arena.n_slots, arena.clip, arena.norms, Bc, 1.0)
         native.clip_reduce_noise(full, arena.clip, None, None, 3, 0, 1.0, inv, arena.summed, arena.grad, Bc, ws)
 

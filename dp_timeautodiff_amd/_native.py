@@ -26,7 +26,7 @@ EXPORTS = {
     "dpk_layernorm_slots": (c_int, [c_int]),
     "dpk_normsq_slots": (c_int, [c_int64]),
     "dpk_linear_grad_sample": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int,
-                                       c_int, c_int, c_int, c_int, c_int64, c_float, c_void_p]),
+                                       c_int, c_int, c_int, c_int, c_int64, c_int, c_float, c_void_p]),
     "dpk_embedding_grad_sample": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int,
                                           c_int, c_int, c_int, c_int, c_int64, c_float, c_void_p]),
     "dpk_layernorm_grad_sample": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int,
@@ -122,7 +122,7 @@ def normsq_slots(P: int) -> int:
 
 
 def linear_grad_sample(A, G, gs_w: FlatView, gs_b: Optional[FlatView], part: torch.Tensor, slot0: int,
-                       g_scale: float):
+                       g_scale: float, ld_w: Optional[int] = None):
     _req(A, "A"); _req(G, "G"); _req(part, "normsq_part"); _req(gs_w.base, "arena")
     if A.dim() != 3 or G.dim() != 3 or not A.is_contiguous() or not G.is_contiguous():
         raise DpkError("A and G must be contiguous [B,T,features]")
@@ -132,14 +132,15 @@ def linear_grad_sample(A, G, gs_w: FlatView, gs_b: Optional[FlatView], part: tor
     out_f = G.shape[2]
     if B == 0:
         return
-    if gs_w.numel != in_f * out_f or (gs_b is not None and gs_b.numel != out_f):
+    ld_w = in_f if ld_w is None else int(ld_w)
+    if ld_w < in_f or gs_w.numel != ld_w * out_f or (gs_b is not None and gs_b.numel != out_f):
         raise DpkError("grad-sample window does not match the layer shape")
     if gs_w.base.shape[0] < B or part.shape[0] < B or part.dim() != 2 or part.stride(1) != 1:
         raise DpkError("arena / partial buffer has fewer rows than the batch")
     if gs_b is not None and gs_b.base.data_ptr() != gs_w.base.data_ptr():
         raise DpkError("weight and bias windows must live in the same arena")
     rc = load().dpk_linear_grad_sample(_ptr(A), _ptr(G), gs_w.ptr, None if gs_b is None else gs_b.ptr,
-                                       _ptr(part), part.stride(0), slot0, B, T, in_f, out_f, gs_w.stride,
+                                       _ptr(part), part.stride(0), slot0, B, T, in_f, out_f, gs_w.stride, ld_w,
                                        float(g_scale), _stream())
     _check(rc, "dpk_linear_grad_sample")
 

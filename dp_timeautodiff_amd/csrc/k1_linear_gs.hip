@@ -63,8 +63,8 @@ __global__ void __launch_bounds__(NW * 64) linear_gs_kernel(const float* __restr
                                                            float* __restrict__ GSw, float* __restrict__ GSb,
                                                            float* __restrict__ normsq_part, int64_t part_stride,
                                                            int slot0, int B, int T, int in_f, int out_f,
-                                                           int64_t gs_stride, float g_scale, int tiles_m,
-                                                           int tiles_n, int vecA, int vecG) {
+                                                           int64_t gs_stride, int ld_w, float g_scale,
+                                                           int tiles_m, int tiles_n, int vecA, int vecG) {
     constexpr int NTHR = NW * 64;
     constexpr int NCG = CS / (32 * NT);        // column groups per tile
     constexpr int UNITS = (RS / 32) * NCG;
@@ -109,13 +109,13 @@ __global__ void __launch_bounds__(NW * 64) linear_gs_kernel(const float* __restr
 #pragma unroll
         for (int j = 0; j < NT; ++j) {
             const int col = wcol0 + j * 32 + l31;
-            if (col < in_f) {
+            if (col < ld_w) {  // columns in [in_f, ld_w) are row padding: written as exact zeros -> whole lines
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     const int row = wrow0 + (r & 3) + 8 * (r >> 2) + 4 * lh;
                     if (row < out_f) {
                         const float v = acc[j][r];
-                        float* p = out + (int64_t)row * in_f + col;
+                        float* p = out + (int64_t)row * ld_w + col;
                         if constexpr (NTS)
                             __builtin_nontemporal_store(v, p);  // whole 128-B lines, read back once much later
                         else
@@ -230,10 +230,10 @@ extern "C" int dpk_linear_slots(int in_features, int out_features) {
 
 extern "C" int dpk_linear_grad_sample(const float* A, const float* G, float* GSw, float* GSb, float* normsq_part,
                                       int64_t part_stride, int slot0, int B, int T, int in_f, int out_f,
-                                      int64_t gs_stride, float g_scale, void* stream) {
+                                      int64_t gs_stride, int ld_w, float g_scale, void* stream) {
     if (!A || !G || !GSw || !normsq_part) return DPK_EINVAL;
     if (B < 0 || T <= 0 || in_f <= 0 || out_f <= 0 || slot0 < 0) return DPK_EINVAL;
-    if (gs_stride < (int64_t)in_f * out_f) return DPK_EINVAL;
+    if (ld_w < in_f || gs_stride < (int64_t)ld_w * out_f) return DPK_EINVAL;
     if (B == 0) return DPK_OK;
     const Plan p = pick_plan(in_f, out_f);
     const int tiles_m = (out_f + p.rs - 1) / p.rs;
@@ -245,15 +245,15 @@ extern "C" int dpk_linear_grad_sample(const float* A, const float* G, float* GSw
     const int vecA = (in_f % 4 == 0) && dpk_aligned16(A);
     const int vecG = (out_f % 4 == 0) && dpk_aligned16(G);
     // whole 128-byte lines per store segment: row stride and every row start multiples of 32 floats
-    const int nt_store = (in_f % 32 == 0) && (gs_stride % 32 == 0) && ((((uintptr_t)GSw) & 127u) == 0);
+    const int nt_store = (ld_w % 32 == 0) && (gs_stride % 32 == 0) && ((((uintptr_t)GSw) & 127u) == 0);
     hipStream_t s = (hipStream_t)stream;
     dim3 grid((unsigned)nblk);
     const bool stream_mode = T <= TK;
     const int lds_rows = stream_mode ? ((T + 1) & ~1) : TK;
 #define DPK_K1_GO(NW, RS, CS, NT, ST, NTS)                                                                       \
     hipLaunchKernelGGL((linear_gs_kernel<NW, RS, CS, NT, ST, NTS>), grid, dim3(NW * 64), lds, s, A, G, GSw, GSb,  \
-                       normsq_part, part_stride, slot0, B, T, in_f, out_f, gs_stride, g_scale, tiles_m, tiles_n,  \
-                       vecA, vecG)
+                       normsq_part, part_stride, slot0, B, T, in_f, out_f, gs_stride, ld_w, g_scale, tiles_m,    \
+                       tiles_n, vecA, vecG)
 #define DPK_K1_LAUNCH(NW, RS, CS, NT)                                                                          \
     do {                                                                                                       \
         const size_t lds = ((size_t)lds_rows * (RS + CS) + NW) * sizeof(float);                                \

@@ -32,11 +32,37 @@ from .layers import RNNLinear
 ARENA_ALIGN = 64  # floats: every parameter window starts on a 256-byte boundary
 
 
+def _row_stride(p: nn.Parameter) -> int:
+    """Arena row stride of a 2-D weight: rows of awkward width (>= 64 and not a multiple of 32 floats) are padded
+    to the next multiple of 32 so that K1 writes whole 128-byte lines (non-temporal) — e.g. 250 -> 256, 400 -> 416."""
+    if p.dim() != 2:
+        return p.shape[-1] if p.dim() else 1
+    n = p.shape[1]
+    return (n + 31) // 32 * 32 if (n >= 64 and n % 32) else n
+
+
 class _ParamWindow:
-    __slots__ = ("name", "param", "offset", "numel")
+    """Where one parameter's per-sample gradient lives inside an arena row (and inside summed/grad)."""
+    __slots__ = ("name", "param", "offset", "numel", "ld")
 
     def __init__(self, name, param, offset):
-        self.name, self.param, self.offset, self.numel = name, param, offset, param.numel()
+        self.name, self.param, self.offset = name, param, offset
+        self.ld = _row_stride(param)
+        self.numel = param.shape[0] * self.ld if param.dim() == 2 else param.numel()
+
+    def view(self, storage: torch.Tensor, lead: Tuple[int, ...] = (), lead_stride: Tuple[int, ...] = (),
+             base: int = 0) -> torch.Tensor:
+        p = self.param
+        if p.dim() == 2:
+            size, stride = tuple(p.shape), (self.ld, 1)
+        else:
+            size = tuple(p.shape)
+            stride, acc = [], 1
+            for d in reversed(size):
+                stride.insert(0, acc)
+                acc *= d
+            stride = tuple(stride)
+        return storage.as_strided(lead + size, lead_stride + stride, base + self.offset)
 
 
 class GradSampleArena:
@@ -58,7 +84,7 @@ class GradSampleArena:
             if p.dtype != torch.float32:
                 raise ValueError(f"{name}: only fp32 parameters are supported (got {p.dtype})")
             self.windows[id(p)] = _ParamWindow(name, p, off)
-            off += (p.numel() + ARENA_ALIGN - 1) // ARENA_ALIGN * ARENA_ALIGN
+            off += (self.windows[id(p)].numel + ARENA_ALIGN - 1) // ARENA_ALIGN * ARENA_ALIGN
         self.P = max(off, ARENA_ALIGN)
         self.n_slots = 0
         self.capacity = 0
@@ -113,12 +139,12 @@ class GradSampleArena:
         return _native.FlatView(self.buf[row0:] if row0 else self.buf, w.offset, w.numel)
 
     def sample_view(self, p: nn.Parameter, row0: int, rows: int) -> torch.Tensor:
-        w = self.windows[id(p)]
-        return self.buf[row0:row0 + rows, w.offset:w.offset + w.numel].view(rows, *p.shape)
+        """[rows, *p.shape] strided view of the per-sample gradients of `p` (rows row0 .. row0+rows)."""
+        return self.windows[id(p)].view(self.buf, (rows,), (self.P,), base=row0 * self.P)
 
     def vec_view(self, vec: torch.Tensor, p: nn.Parameter) -> torch.Tensor:
-        w = self.windows[id(p)]
-        return vec[w.offset:w.offset + w.numel].view(p.shape)
+        """p-shaped (possibly row-padded) view into a [P] vector laid out like an arena row."""
+        return self.windows[id(p)].view(vec)
 
     @property
     def rows(self) -> int:
@@ -395,7 +421,8 @@ class GradSampleModule(nn.Module):
         if B > 0:
             if layer.kind == "linear":
                 vb = arena.flat(m.bias, row0) if m.bias is not None else None
-                _native.linear_grad_sample(A, G, arena.flat(m.weight, row0), vb, part, layer.slot0, g_scale)
+                _native.linear_grad_sample(A, G, arena.flat(m.weight, row0), vb, part, layer.slot0, g_scale,
+                                           ld_w=arena.window(m.weight).ld)
             elif layer.kind == "embedding":
                 _native.embedding_grad_sample(A, G, arena.flat(m.weight, row0), m.num_embeddings, part,
                                               layer.slot0, g_scale)

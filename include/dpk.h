@@ -56,13 +56,15 @@ int dpk_normsq_slots(int64_t P);
  *     GSw[b,o,i] = sum_t (g_scale*G[b,t,o]) * A[b,t,i]        GSb[b,o] = sum_t g_scale*G[b,t,o]
  * A [B,T,in], G [B,T,out] contiguous.  GSw/GSb rows of sample b start at b*gs_stride floats
  * (gs_stride = row length of the flat per-sample-gradient arena).  GSb may be NULL (no bias).
+ * ld_w >= in is the row stride of GSw[b] (the arena pads rows of awkward widths to a multiple of 32 floats so
+ * that every store is a whole 128-byte line); columns [in, ld_w) are written as zeros.
  * g_scale = batch size for loss_reduction="mean" (Opacus multiplies backprops by n first; so do we).
  * Writes dpk_linear_slots(in,out) normsq partials per sample, covering weight and bias.
  */
 int dpk_linear_grad_sample(const float* A, const float* G, float* GSw, float* GSb,
                            float* normsq_part, int64_t part_stride, int slot0,
                            int B, int T, int in_features, int out_features,
-                           int64_t gs_stride, float g_scale, void* stream);
+                           int64_t gs_stride, int ld_w, float g_scale, void* stream);
 
 /*
  * K3 — per-sample gradient of nn.Embedding.  Replaces Opacus' Embedding sampler

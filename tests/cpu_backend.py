@@ -22,13 +22,17 @@ def normsq_slots(P):
     return 1
 
 
-def linear_grad_sample(A, G, gs_w, gs_b, part, slot0, g_scale):
+def linear_grad_sample(A, G, gs_w, gs_b, part, slot0, g_scale, ld_w=None):
     B = A.shape[0]
     if B == 0:
         return
     assert A.is_contiguous() and G.is_contiguous() and A.dim() == 3 and G.dim() == 3
     gw, gb = O.linear_grad_sample(A, G * g_scale, gs_b is not None)
-    _win(gs_w, B).copy_(gw.reshape(B, -1))
+    out_f, in_f = gw.shape[1:]
+    ld = in_f if ld_w is None else ld_w
+    w = _win(gs_w, B).view(B, out_f, ld)
+    w.zero_()
+    w[:, :, :in_f] = gw
     part[:B, slot0] = (gw.reshape(B, -1) ** 2).sum(1)
     part[:B, slot0 + 1] = 0.0
     if gs_b is not None:

@@ -47,14 +47,14 @@ def _fill(model, seed):
 
 
 def _arena_noise(opt, names, params, flat_noise, dev):
-    """Lay a reference-ordered flat noise vector out in arena order."""
+    """Lay a reference-ordered flat noise vector out like an arena row (windows may be row-padded)."""
     arena = opt.arena
     z = torch.zeros(arena.P)
     off = 0
     for p in params:
-        w = arena.window(p)
-        z[w.offset:w.offset + w.numel] = torch.from_numpy(flat_noise[off:off + w.numel])
-        off += w.numel
+        n = p.numel()
+        arena.vec_view(z, p).copy_(torch.from_numpy(flat_noise[off:off + n]).view(p.shape))
+        off += n
     return z.to(dev)
 
 

@@ -67,6 +67,31 @@ def test_linear_grad_sample(nat, B, T, in_f, out_f, bias):
     assert rel_err(p[:, 2:2 + slots].double().sum(1).numpy(), ref_sq.numpy()) < TOL
 
 
+@pytest.mark.parametrize("B,T,in_f,out_f", [(5, 24, 400, 200), (3, 48, 250, 1000), (4, 24, 208, 208), (2, 48, 500, 70)])
+def test_linear_grad_sample_padded_rows(nat, B, T, in_f, out_f):
+    """Row stride ld > in (arena pads awkward widths to whole 128-byte lines): pads are written as zeros."""
+    from oracle import opacus_ref as O
+    g = torch.Generator().manual_seed(in_f)
+    A = torch.randn(B, T, in_f, generator=g)
+    G = torch.randn(B, T, out_f, generator=g)
+    ld = (in_f + 31) // 32 * 32
+    gw_ref, gb_ref = O.linear_grad_sample(A, G * float(B), True)
+    nw = ld * out_f
+    base = torch.full((B, 64 + nw + out_f + 64), 7.0, device="cuda")
+    off = 64
+    part = torch.zeros(B, nat.linear_slots(in_f, out_f), device="cuda")
+    nat.linear_grad_sample(A.cuda(), G.cuda(), nat.FlatView(base, off, nw), nat.FlatView(base, off + nw, out_f), part,
+                           0, float(B), ld_w=ld)
+    out = base.cpu()
+    w = out[:, off:off + nw].reshape(B, out_f, ld)
+    assert rel_err(w[:, :, :in_f].numpy(), gw_ref.numpy()) < TOL
+    assert (w[:, :, in_f:] == 0).all()
+    assert rel_err(out[:, off + nw:off + nw + out_f].numpy(), gb_ref.numpy()) < TOL
+    assert (out[:, :off] == 7).all() and (out[:, off + nw + out_f:] == 7).all()
+    ref_sq = (gw_ref.double() ** 2).sum((1, 2)) + (gb_ref.double() ** 2).sum(1)
+    assert rel_err(part.cpu().double().sum(1).numpy(), ref_sq.numpy()) < TOL
+
+
 def test_linear_grad_sample_is_deterministic(nat):
     g = torch.Generator().manual_seed(5)
     A = torch.randn(16, 24, 400, generator=g).cuda()

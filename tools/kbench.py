@@ -15,13 +15,14 @@ def timeit(fn, iters=20, warm=3):
 
 def bench_linear(B, T, in_f, out_f):
     A = torch.randn(B, T, in_f, device="cuda"); G = torch.randn(B, T, out_f, device="cuda")
-    n = in_f * out_f
-    stride = (n + out_f + 63) // 64 * 64
+    ld = (in_f + 31) // 32 * 32 if (in_f >= 64 and in_f % 32) else in_f
+    n = ld * out_f
+    stride = (n + 63) // 64 * 64 + 64
     base = torch.zeros(B, stride, device="cuda")
     part = torch.zeros(B, nat.linear_slots(in_f, out_f), device="cuda")
-    vw = nat.FlatView(base, 0, n); vb = nat.FlatView(base, n, out_f)
-    ms = timeit(lambda: nat.linear_grad_sample(A, G, vw, vb, part, 0, float(B)))
-    wbytes = B * (n + out_f) * 4; rbytes = B * T * (in_f + out_f) * 4
+    vw = nat.FlatView(base, 0, n); vb = nat.FlatView(base, (n + 63) // 64 * 64, out_f) if out_f <= 64 else None
+    ms = timeit(lambda: nat.linear_grad_sample(A, G, vw, vb, part, 0, float(B), ld_w=ld))
+    wbytes = B * (in_f * out_f) * 4; rbytes = B * T * (in_f + out_f) * 4
     flops = 2.0 * B * T * n
     print(f"K1 B={B} T={T} in={in_f} out={out_f}: {ms*1e3:8.1f} us  write {wbytes/ms/1e6:7.1f} GB/s  alg {(wbytes+rbytes)/ms/1e6:7.1f} GB/s  {flops/ms/1e9:6.1f} TFLOP/s")
 
@@ -44,6 +45,10 @@ if __name__ == "__main__":
         bench_linear(1024, 24, 512, 512)
         bench_linear(1024, 24, 32, 128)
         bench_linear(512, 48, 250, 1000)
+        bench_linear(512, 48, 1000, 250)
+        bench_linear(512, 48, 250, 250)
+        bench_linear(512, 48, 256, 1024)
+        bench_linear(512, 48, 512, 1024)
         bench_linear(512, 48, 500, 1000)
         bench_linear(128, 256, 2048, 2048)
         bench_linear(256, 256, 1024, 512)
