@@ -42,6 +42,8 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--eager", action="store_true", help="launch every kernel from Python instead of replaying a hipGraph")
     ap.add_argument("--cpu-sample", type=int, default=None)
+    ap.add_argument("--hooked-gru", action="store_true",
+                    help="keep the reference's T-step GRU loop + per-call hooks instead of the fused K8 recurrence")
     return ap.parse_args()
 
 
@@ -129,7 +131,8 @@ def main():
     from dp_timeautodiff_amd.optimizer import DistributedDPOptimizer, DPOptimizer
     _native.load()
 
-    wl = workloads.build(args.config, dev, batch=args.batch, seed_offset=rank * 1000)
+    wl = workloads.build(args.config, dev, batch=args.batch, seed_offset=rank * 1000,
+                         fuse_recurrence=not args.hooked_gru)
     B = wl.B
     phys = args.physical_batch or (512 if args.config == "cfg5" else B)
     model = wl.model
@@ -225,6 +228,7 @@ def main():
                    "per_gpu_batch": B, "global_batch": B * world, "physical_batch": phys,
                    "params": wl.n_params, "parallelism": f"dp{world}",
                    "step": "zero_grad+forward+backward(hooks: K1/K3/K4)+DPOptimizer.step(K6,K7)+Adam",
+                   "gru": "hooked T-step loop" if args.hooked_gru else "fused K8 recurrence",
                    "launch": ("hipGraph replay of the captured step" + (" (local part; all-reduce+noise+Adam eager)"
                               if world > 1 else "")) if graphed is not None else "eager"},
         "roofline": roof, "roofline_k1": k1_roof, "hot_path": hot, "final_loss": final_loss,

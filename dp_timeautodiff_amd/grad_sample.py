@@ -28,6 +28,7 @@ import torch.nn as nn
 
 from . import _native
 from .layers import RNNLinear
+from .layers.fused_gru import FusedLinearCellGRU
 
 ARENA_ALIGN = 64  # floats: every parameter window starts on a 256-byte boundary
 
@@ -240,6 +241,12 @@ class GradSampleModule(nn.Module):
             self._handles.append(sub.register_forward_pre_hook(self._make_pre(layer)))
             self._handles.append(sub.register_forward_hook(self._make_fwd(layer)))
             self._handles.append(sub.register_full_backward_hook(self._make_bwd(layer)))
+        # fused recurrences hand their gates' stacked (activations, backprops) over directly (no per-call hooks)
+        self._by_module = {id(l.module): l for l in self._layers}
+        for sub in m.modules():
+            if isinstance(sub, FusedLinearCellGRU):
+                object.__setattr__(sub, "_dpk_sink", self._fused_sink)
+                object.__setattr__(sub, "_dpk_sink_active", lambda: self.hooks_enabled)
         for n_, p in params:
             p.grad_sample = None
             p._forward_counter = 0
@@ -303,6 +310,9 @@ class GradSampleModule(nn.Module):
 
     def _close(self):
         self.remove_hooks()
+        for sub in self._module.modules():
+            if isinstance(sub, FusedLinearCellGRU):
+                sub._init_runtime()
         for p in self._module.parameters():
             for attr in ("grad_sample", "_forward_counter", "_dpk_arena", "summed_grad"):
                 if hasattr(p, attr):
@@ -398,6 +408,15 @@ class GradSampleModule(nn.Module):
         else:
             A = self._stack([p[0] for p in pairs], 1)
         G = self._stack([p[1] for p in pairs], 1)
+        self._emit(layer, A, G)
+
+    def _fused_sink(self, module: nn.Module, A: torch.Tensor, G: torch.Tensor):
+        self._emit(self._by_module[id(module)], A, G)
+
+    def _emit(self, layer: _Layer, A: torch.Tensor, G: torch.Tensor):
+        """Contract one layer's stacked activations A and backprops G into its arena window."""
+        arena = self.arena
+        m = layer.module
         if G.dtype != torch.float32 or (layer.kind != "embedding" and A.dtype != torch.float32):
             raise _native.DpkError(f"{layer.name}: only fp32 activations/backprops are supported")
         B = A.shape[0]

@@ -25,6 +25,7 @@ from .accountants.utils import get_noise_multiplier
 from .data_loader import DPDataLoader, switch_generator
 from .distributed import DifferentiallyPrivateDistributedDataParallel as DPDDP
 from .grad_sample import GradSampleModule
+from .layers.fused_gru import fuse_recurrences
 from .optimizer import DistributedDPOptimizer, DPOptimizer
 from .validators import ModuleValidator
 
@@ -35,6 +36,7 @@ class PrivacyEngine:
         self.secure_mode = secure_mode
         self.secure_rng = None
         self.dataset = None  # only used to detect switching to a different dataset
+        self.fuse_recurrence = True  # make_private(fuse_recurrence=False) keeps the hooked T-call protocol
         if self.secure_mode:
             # the Philox stream is keyed from os.urandom either way; a CSPRNG-backed torch generator
             # (torchcsprng) is not available in this image
@@ -84,6 +86,10 @@ class PrivacyEngine:
                                  f"loss_reduction: {loss_reduction}. Please pass vanilla nn.Module instead")
             return module
         inner = module.module if isinstance(module, DPDDP) else module
+        if self.fuse_recurrence and next(inner.parameters()).is_cuda:
+            # CustomGRU-shaped loops -> the K8 recurrence kernels (same Linear submodules and parameters, so the
+            # optimizer built on them stays valid)
+            inner = fuse_recurrences(inner)
         return GradSampleModule(inner, batch_first=batch_first, loss_reduction=loss_reduction)
 
     def is_compatible(self, *, module: nn.Module, optimizer: Optional[optim.Optimizer],
@@ -110,6 +116,7 @@ class PrivacyEngine:
                      ) -> Tuple[GradSampleModule, DPOptimizer, DataLoader]:
         if noise_generator and self.secure_mode:
             raise ValueError("Passing seed is prohibited in secure mode")
+        self.fuse_recurrence = bool(kwargs.pop("fuse_recurrence", getattr(self, "fuse_recurrence", True)))
 
         # compare module parameter with optimizer parameters
         model_parameters = set(module.parameters())

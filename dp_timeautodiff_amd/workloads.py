@@ -11,6 +11,7 @@ from typing import Callable, Dict
 import torch
 
 from . import models
+from .layers.fused_gru import fuse_recurrences
 
 CONFIGS: Dict[str, dict] = {
     # name: kind, per-GPU batch, dims
@@ -42,7 +43,7 @@ def _linear_dims(model):
     return dims
 
 
-def build(name: str, device, batch: int = None, seed_offset: int = 0) -> Workload:
+def build(name: str, device, batch: int = None, seed_offset: int = 0, fuse_recurrence: bool = True) -> Workload:
     c = dict(CONFIGS[name])
     B = batch or c["B"]
     torch.manual_seed(0)
@@ -52,6 +53,8 @@ def build(name: str, device, batch: int = None, seed_offset: int = 0) -> Workloa
     if c["kind"] == "vae":
         K, H = c["K"], c["H"]
         model = models.DeapStackDP(64, B, T, 0, 0, K, [], K, H, 1, 128, 8, 7).to(device).train()
+        if fuse_recurrence and torch.device(device).type == "cuda":
+            model = fuse_recurrences(model)  # what PrivacyEngine.make_private does to CustomGRU-shaped modules
         x = torch.rand(B, T, K, generator=gd).to(device)
         eps = torch.randn(B, T, 7, generator=ge).to(device)
 

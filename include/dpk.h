@@ -142,6 +142,34 @@ int dpk_clip_reduce_noise(const float* GS, int64_t gs_stride, const float* clip,
 /* Philox normal stream on its own (tests; also lets host code pre-draw the shared noise). */
 int dpk_philox_normal(float* out, int64_t n, uint64_t seed, uint64_t offset, float std, void* stream);
 
+/*
+ * K8 — fused Linear-cell GRU recurrence: the caller either side of K1.  Replaces the T-step
+ * Python loop of CustomGRU.forward (Model_Code/timeautoencoder.py:74-96: cat -> update_gate/reset_gate ->
+ * cat -> new_gate -> blend, per time step) and its autograd backward with ONE launch each.  x has already been
+ * through input_layer (xp [B,T,H]).  Gate weights are nn.Linear(2H, H) weights, pre-packed into MFMA fragment
+ * order by dpk_gru_pack (dpk_gru_pack_floats(O,K) floats per packed matrix):
+ *   W(out,k) = transposed ? src[k*ld + coff + out] : src[out*ld + coff + k],  out < O, k < K.
+ * H must be a multiple of 8 and at most 512 (DPK_ERANGE otherwise).
+ *
+ * forward:  Pz/Pr/Pn = pack(W_update / W_reset / W_new, O=H, K=2H).  h0 [B,H] nullable (zeros).
+ *   writes out = h_t, Z, R, N (gate activations) and RH = r_t * h_{t-1}, all [B,T,H].
+ * backward: dout [B,T,H] = dL/dout; dhT [B,H] nullable = dL/dh_T on top of dout[:,T-1];
+ *   Pnx  = pack(W_new,            transposed, coff=0, O=H, K=H)     Pnh  = same with coff=H
+ *   Pzrx = pack([W_update;W_reset], transposed, coff=0, O=H, K=2H)  Pzrh = same with coff=H
+ *   writes dxp [B,T,H] and the gates' pre-activation gradients Gz, Gr, Gn [B,T,H] — the stacked backprops that
+ *   dpk_linear_grad_sample contracts (K = T) with A_zr = [xp | h_{t-1}] (update, reset) and A_n = [xp | RH] (new);
+ *   dh0 [B,H] nullable.
+ */
+int64_t dpk_gru_pack_floats(int O, int K);
+int dpk_gru_pack(const float* src, int ld, int coff, int O, int K, int transposed, float* dst, void* stream);
+int dpk_gru_forward(const float* xp, const float* h0, const float* Pz, const float* Pr, const float* Pn,
+                    const float* bz, const float* br, const float* bn, float* out, float* Z, float* R,
+                    float* N, float* RH, int B, int T, int H, void* stream);
+int dpk_gru_backward(const float* dout, const float* dhT, const float* Z, const float* R, const float* N,
+                     const float* hall, const float* h0, const float* Pnx, const float* Pnh,
+                     const float* Pzrx, const float* Pzrh, float* dxp, float* Gz, float* Gr, float* Gn,
+                     float* dh0, int B, int T, int H, void* stream);
+
 #ifdef __cplusplus
 }
 #endif
