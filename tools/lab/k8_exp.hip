@@ -19,20 +19,17 @@
 // The backward kernel also emits the gates' pre-activation gradients G_z, G_r, G_n [B,T,H] — exactly the stacked
 // backprops K1 contracts with the stacked activations [x_t | h_{t-1}] / [x_t | r*h_{t-1}] (K = T) — so the hooked
 // T-call protocol (T stash + T pop + torch.stack) disappears for these layers.
-#include "dpk_common.h"
+#include "../../dp_timeautodiff_amd/csrc/dpk_common.h"
 
+__device__ int k8_flags_dev = K8_FLAGS;
+#define K8_ST (k8_flags_dev & 1)
+#define K8_XP (k8_flags_dev & 2)
+#define K8_WL (k8_flags_dev & 4)
 namespace {
 
 constexpr int GBT = 16;  // batch rows per workgroup
 
-// v_exp_f32 / v_rcp_f32 (about 1 ulp each): the gates are bounded, so absolute error ~1e-7 is the fp32 noise floor
-__device__ __forceinline__ float sigmoidf_(float x) { return __frcp_rn(1.0f + __expf(-x)); }
-
-__device__ __forceinline__ float tanhf_(float x) { return 1.0f - 2.0f * __frcp_rn(1.0f + __expf(2.0f * x)); }
-
-// Workgroup barrier that orders LDS traffic only.  __syncthreads() also drains vmcnt, i.e. waits for the acks of the
-// global stores issued just before it (~1 us each time step); nothing here communicates through global memory.
-__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+__device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + expf(-x)); }
 
 // dst[((ot*KG + kg)*64 + l)*4 + m] = W(out = ot*16 + (l&15), k = kg*16 + m*4 + (l>>4)), zero outside O x K.
 // W(out,k) = transposed ? src[k*ld + coff + out] : src[out*ld + coff + k]
@@ -55,23 +52,8 @@ __global__ void __launch_bounds__(256) gru_pack_kernel(const float* __restrict__
 
 constexpr int GNW = 8;   // waves per workgroup (2 per SIMD: one wave's weight loads hide behind the other's MFMAs)
 
-// acc += W-tile x LDS operand, K in groups of 16 (4 MFMAs per 16-byte weight load).  A ring of GPF weight groups is
-// kept in flight (L2 latency ~ 3 groups of MFMA issue); the main loop is branch-free so that every ring slot stays in
-// fixed registers: a slot is refilled right after the MFMAs that consumed it have issued.
-#define DPK_MFMA4(ACC, W, B0, B1, B2, B3)                                   \
-    ACC = __builtin_amdgcn_mfma_f32_16x16x4f32((W).x, B0, ACC, 0, 0, 0);    \
-    ACC = __builtin_amdgcn_mfma_f32_16x16x4f32((W).y, B1, ACC, 0, 0, 0);    \
-    ACC = __builtin_amdgcn_mfma_f32_16x16x4f32((W).z, B2, ACC, 0, 0, 0);    \
-    ACC = __builtin_amdgcn_mfma_f32_16x16x4f32((W).w, B3, ACC, 0, 0, 0)
-
-struct BFrag {  // B operand of one K group: 4 MFMAs x one float per lane
-    float b0, b1, b2, b3;
-};
-__device__ __forceinline__ BFrag ld_bfrag(const float* p) { return BFrag{p[0], p[4 * GBT], p[8 * GBT], p[12 * GBT]}; }
-
-// The steady-state block is scheduled by hand (sched_barrier pins the order): LDS operand of group k+1 is read before
-// the MFMAs of group k issue, and slot s is refilled immediately after its MFMAs, so GPF-1 groups of weight loads
-// stay in flight.  Left alone, the compiler sinks all refills to the end of the block and exposes the L2 latency.
+// acc += W-tile x LDS operand, K in groups of 16 (4 MFMAs per 16-byte weight load); GPF groups of weights are in
+// flight (L2 latency ~ 3 groups of MFMA issue)
 template <int GPF>
 __device__ __forceinline__ void mfma_tile(f32x4& acc, const f32x4* __restrict__ wp, const float* __restrict__ sB, int KG,
                                           int lane) {
@@ -80,41 +62,22 @@ __device__ __forceinline__ void mfma_tile(f32x4& acc, const f32x4* __restrict__ 
     const f32x4* pw = wp + lane;
     f32x4 w[GPF];
 #pragma unroll
-    for (int s = 0; s < GPF; ++s) w[s] = pw[(s < KG ? s : KG - 1) * 64];
-    BFrag bc = ld_bfrag(p);
-    int kg = 0;
-    for (; kg + 2 * GPF <= KG; kg += GPF) {  // every refill of these blocks is in range
+    for (int s = 0; s < GPF; ++s) w[s] = pw[(int64_t)(s < KG ? s : KG - 1) * 64];
+    for (int kg0 = 0; kg0 < KG; kg0 += GPF) {
 #pragma unroll
         for (int s = 0; s < GPF; ++s) {
-            p += 16 * GBT;
-            const BFrag bn = ld_bfrag(p);  // kg + s + 1 < KG here
-            __builtin_amdgcn_sched_barrier(0);
-            DPK_MFMA4(acc, w[s], bc.b0, bc.b1, bc.b2, bc.b3);
-            w[s] = pw[(kg + s + GPF) * 64];
-            __builtin_amdgcn_sched_barrier(0);
-            bc = bn;
-        }
-    }
-    const int rem = KG - kg;  // < 2*GPF groups left: first block refills only what exists, second block none
-#pragma unroll
-    for (int s = 0; s < GPF; ++s) {
-        if (s < rem) {
-            const float* pn = p + (s + 1 < rem ? 16 * GBT : 0);
-            const BFrag bn = ld_bfrag(pn);
-            DPK_MFMA4(acc, w[s], bc.b0, bc.b1, bc.b2, bc.b3);
-            if (s + GPF < rem) w[s] = pw[(kg + s + GPF) * 64];
-            p = pn;
-            bc = bn;
-        }
-    }
-#pragma unroll
-    for (int s = 0; s < GPF; ++s) {
-        if (s + GPF < rem) {
-            const float* pn = p + (s + GPF + 1 < rem ? 16 * GBT : 0);
-            const BFrag bn = ld_bfrag(pn);
-            DPK_MFMA4(acc, w[s], bc.b0, bc.b1, bc.b2, bc.b3);
-            p = pn;
-            bc = bn;
+            const int kg = kg0 + s;
+            if (kg < KG) {
+                const float b0 = p[0], b1 = p[4 * GBT], b2 = p[8 * GBT], b3 = p[12 * GBT];
+                const f32x4 c = w[s];
+                const int nx = kg + GPF < KG ? kg + GPF : KG - 1;
+                if (K8_WL) w[s] = pw[(int64_t)nx * 64];
+                acc = __builtin_amdgcn_mfma_f32_16x16x4f32(c.x, b0, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_16x16x4f32(c.y, b1, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_16x16x4f32(c.z, b2, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_16x16x4f32(c.w, b3, acc, 0, 0, 0);
+                p += 16 * GBT;
+            }
         }
     }
 }
@@ -130,51 +93,30 @@ __device__ __forceinline__ void mfma_tile2(f32x4& a0, f32x4& a1, const f32x4* __
     f32x4 w0[GPF], w1[GPF];
 #pragma unroll
     for (int s = 0; s < GPF; ++s) {
-        const int o = (s < KG ? s : KG - 1) * 64;
+        const int64_t o = (int64_t)(s < KG ? s : KG - 1) * 64;
         w0[s] = pw0[o];
         w1[s] = pw1[o];
     }
-    BFrag bc = ld_bfrag(p);
-    int kg = 0;
-    for (; kg + 2 * GPF <= KG; kg += GPF) {
+    for (int kg0 = 0; kg0 < KG; kg0 += GPF) {
 #pragma unroll
         for (int s = 0; s < GPF; ++s) {
-            p += 16 * GBT;
-            const BFrag bn = ld_bfrag(p);
-            __builtin_amdgcn_sched_barrier(0);
-            DPK_MFMA4(a0, w0[s], bc.b0, bc.b1, bc.b2, bc.b3);
-            w0[s] = pw0[(kg + s + GPF) * 64];
-            DPK_MFMA4(a1, w1[s], bc.b0, bc.b1, bc.b2, bc.b3);
-            w1[s] = pw1[(kg + s + GPF) * 64];
-            __builtin_amdgcn_sched_barrier(0);
-            bc = bn;
-        }
-    }
-    const int rem = KG - kg;
-#pragma unroll
-    for (int s = 0; s < GPF; ++s) {
-        if (s < rem) {
-            const float* pn = p + (s + 1 < rem ? 16 * GBT : 0);
-            const BFrag bn = ld_bfrag(pn);
-            DPK_MFMA4(a0, w0[s], bc.b0, bc.b1, bc.b2, bc.b3);
-            DPK_MFMA4(a1, w1[s], bc.b0, bc.b1, bc.b2, bc.b3);
-            if (s + GPF < rem) {
-                w0[s] = pw0[(kg + s + GPF) * 64];
-                w1[s] = pw1[(kg + s + GPF) * 64];
+            const int kg = kg0 + s;
+            if (kg < KG) {
+                const float b0 = p[0], b1 = p[4 * GBT], b2 = p[8 * GBT], b3 = p[12 * GBT];
+                const f32x4 c0 = w0[s], c1 = w1[s];
+                const int64_t nx = (int64_t)(kg + GPF < KG ? kg + GPF : KG - 1) * 64;
+                if (K8_WL) w0[s] = pw0[nx];
+                if (K8_WL) w1[s] = pw1[nx];
+                a0 = __builtin_amdgcn_mfma_f32_16x16x4f32(c0.x, b0, a0, 0, 0, 0);
+                a1 = __builtin_amdgcn_mfma_f32_16x16x4f32(c1.x, b0, a1, 0, 0, 0);
+                a0 = __builtin_amdgcn_mfma_f32_16x16x4f32(c0.y, b1, a0, 0, 0, 0);
+                a1 = __builtin_amdgcn_mfma_f32_16x16x4f32(c1.y, b1, a1, 0, 0, 0);
+                a0 = __builtin_amdgcn_mfma_f32_16x16x4f32(c0.z, b2, a0, 0, 0, 0);
+                a1 = __builtin_amdgcn_mfma_f32_16x16x4f32(c1.z, b2, a1, 0, 0, 0);
+                a0 = __builtin_amdgcn_mfma_f32_16x16x4f32(c0.w, b3, a0, 0, 0, 0);
+                a1 = __builtin_amdgcn_mfma_f32_16x16x4f32(c1.w, b3, a1, 0, 0, 0);
+                p += 16 * GBT;
             }
-            p = pn;
-            bc = bn;
-        }
-    }
-#pragma unroll
-    for (int s = 0; s < GPF; ++s) {
-        if (s + GPF < rem) {
-            const float* pn = p + (s + GPF + 1 < rem ? 16 * GBT : 0);
-            const BFrag bn = ld_bfrag(pn);
-            DPK_MFMA4(a0, w0[s], bc.b0, bc.b1, bc.b2, bc.b3);
-            DPK_MFMA4(a1, w1[s], bc.b0, bc.b1, bc.b2, bc.b3);
-            p = pn;
-            bc = bn;
         }
     }
 }
@@ -247,8 +189,8 @@ __global__ void __launch_bounds__(GNW * 64) gru_fwd_kernel(const float* __restri
                 lds_col4(bufB, k4 * 4, jj, xpre[i]);
             }
         }
-        lds_barrier();
-        if (PRE && t + 1 < T) load_x(t + 1);
+        __syncthreads();
+        if (K8_XP && PRE && t + 1 < T) load_x(t + 1);
         // ---- phase 1: z, r ; r*h -> bufB ------------------------------------------------------------------
 #pragma unroll
         for (int i = 0; i < TPW; ++i) {
@@ -267,14 +209,14 @@ __global__ void __launch_bounds__(GNW * 64) gru_fwd_kernel(const float* __restri
                     lds_col4(bufB, H + o, j, rh);
                     if (bvalid) {
                         const int64_t g = ((int64_t)b * T + t) * H + o;
-                        st4(Z + g, z);
-                        st4(R + g, r);
-                        st4(RH + g, rh);
+                        if (K8_ST) st4(Z + g, z);
+                        if (K8_ST) st4(R + g, r);
+                        if (K8_ST) st4(RH + g, rh);
                     }
                 }
             }
         }
-        lds_barrier();
+        __syncthreads();
         // ---- phase 2: n, h' ---------------------------------------------------------------------------------
 #pragma unroll
         for (int i = 0; i < TPW; ++i) {
@@ -286,20 +228,20 @@ __global__ void __launch_bounds__(GNW * 64) gru_fwd_kernel(const float* __restri
                 mfma_tile<(TPW < 4 ? 4 : 2)>(an, Pn + (int64_t)ot * KG * 64, bufB, KG, lane);
                 if (o < H) {
                     f32x4 n;
-                    n.x = tanhf_(an.x); n.y = tanhf_(an.y); n.z = tanhf_(an.z); n.w = tanhf_(an.w);
+                    n.x = tanhf(an.x); n.y = tanhf(an.y); n.z = tanhf(an.z); n.w = tanhf(an.w);
                     const f32x4 z = zreg[i];
                     const f32x4 hn = (1.0f - z) * n + z * hreg[i];
                     hreg[i] = hn;
                     lds_col4(bufA, H + o, j, hn);  // phase-1 reads of bufA finished at the barrier above
                     if (bvalid) {
                         const int64_t g = ((int64_t)b * T + t) * H + o;
-                        st4(N + g, n);
-                        st4(out + g, hn);
+                        if (K8_ST) st4(N + g, n);
+                        if (K8_ST) st4(out + g, hn);
                     }
                 }
             }
         }
-        lds_barrier();  // bufB's x rows are rewritten at the top of the next step
+        __syncthreads();  // bufB's x rows are rewritten at the top of the next step
     }
 }
 
@@ -373,15 +315,15 @@ __global__ void __launch_bounds__(GNW * 64) gru_bwd_kernel(const float* __restri
                 dhc[i] = dh * z;
                 if (bvalid) {
                     const int64_t g = ((int64_t)b * T + t) * H + o;
-                    st4(Gn + g, dnp);
-                    st4(Gz + g, dzp);
+                    if (K8_ST) st4(Gn + g, dnp);
+                    if (K8_ST) st4(Gz + g, dzp);
                 }
                 lds_col4(sDn, o, j, dnp);   // rows of batch columns beyond B are zeros (operands were zero)
                 lds_col4(sDzr, o, j, dzp);
             }
         }
-        lds_barrier();
-        if (PRE && t > 0) load_step(t - 1);
+        __syncthreads();
+        if (K8_XP && PRE && t > 0) load_step(t - 1);
         // ---- GEMM1: d[x | r*h] = Wn^T dn_pre ; dr_pre -> sDzr --------------------------------------------------
 #pragma unroll
         for (int i = 0; i < TPW; ++i) {
@@ -396,11 +338,11 @@ __global__ void __launch_bounds__(GNW * 64) gru_bwd_kernel(const float* __restri
                     const f32x4 drp = ah * hpreg[i] * r * (1.0f - r);
                     dhc[i] += ah * r;
                     lds_col4(sDzr, H + o, j, drp);
-                    if (bvalid) st4(Gr + ((int64_t)b * T + t) * H + o, drp);
+                    if (bvalid) if (K8_ST) st4(Gr + ((int64_t)b * T + t) * H + o, drp);
                 }
             }
         }
-        lds_barrier();
+        __syncthreads();
         // ---- GEMM2: d[x | h] += [Wz;Wr]^T [dz_pre | dr_pre] ------------------------------------------------------
 #pragma unroll
         for (int i = 0; i < TPW; ++i) {
@@ -411,17 +353,17 @@ __global__ void __launch_bounds__(GNW * 64) gru_bwd_kernel(const float* __restri
                 mfma_tile2<(TPW < 4 ? 4 : 2)>(accx[i], ah, Pzrx + (int64_t)ot * KGzr * 64, Pzrh + (int64_t)ot * KGzr * 64, sDzr, KGzr, lane);
                 if (o < H) {
                     dhc[i] += ah;
-                    if (bvalid) st4(dxp + ((int64_t)b * T + t) * H + o, accx[i]);
+                    if (bvalid) if (K8_ST) st4(dxp + ((int64_t)b * T + t) * H + o, accx[i]);
                 }
             }
         }
-        lds_barrier();  // sDn / sDzr are rewritten by the next (earlier) time step
+        __syncthreads();  // sDn / sDzr are rewritten by the next (earlier) time step
     }
     if (dh0) {
 #pragma unroll
         for (int i = 0; i < TPW; ++i) {
             const int o = (wave + GNW * i) * 16 + q * 4;
-            if (wave + GNW * i < NT && o < H && bvalid) st4(dh0 + (int64_t)b * H + o, dhc[i]);
+            if (wave + GNW * i < NT && o < H && bvalid) if (K8_ST) st4(dh0 + (int64_t)b * H + o, dhc[i]);
         }
     }
 }

@@ -19,8 +19,11 @@
 // The backward kernel also emits the gates' pre-activation gradients G_z, G_r, G_n [B,T,H] — exactly the stacked
 // backprops K1 contracts with the stacked activations [x_t | h_{t-1}] / [x_t | r*h_{t-1}] (K = T) — so the hooked
 // T-call protocol (T stash + T pop + torch.stack) disappears for these layers.
-#include "dpk_common.h"
+#include "../../dp_timeautodiff_amd/csrc/dpk_common.h"
 
+__device__ long long k8_dbg[128];
+extern "C" int k8_dbg_read(long long* h) { return (int)hipMemcpyFromSymbol(h, HIP_SYMBOL(k8_dbg), sizeof(long long) * 128); }
+#define TICK(n) do { long long now_ = clock64(); if (dbg) acc_[n] += now_ - last_; last_ = now_; if (blockIdx.x == 0 && lane == 0 && t == 5) k8_dbg[16 + wave * 8 + n] = now_; } while (0)
 namespace {
 
 constexpr int GBT = 16;  // batch rows per workgroup
@@ -234,6 +237,9 @@ __global__ void __launch_bounds__(GNW * 64) gru_fwd_kernel(const float* __restri
         }
     };
     if (PRE) load_x(0);
+    const bool dbg = blockIdx.x == 0 && threadIdx.x == 0;
+    long long acc_[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    long long last_ = clock64();
 
     for (int t = 0; t < T; ++t) {
         if (!PRE) load_x(t);  // widest tiles: no registers to spare for the prefetch
@@ -247,7 +253,9 @@ __global__ void __launch_bounds__(GNW * 64) gru_fwd_kernel(const float* __restri
                 lds_col4(bufB, k4 * 4, jj, xpre[i]);
             }
         }
+        TICK(0);
         lds_barrier();
+        TICK(1);
         if (PRE && t + 1 < T) load_x(t + 1);
         // ---- phase 1: z, r ; r*h -> bufB ------------------------------------------------------------------
 #pragma unroll
@@ -258,6 +266,8 @@ __global__ void __launch_bounds__(GNW * 64) gru_fwd_kernel(const float* __restri
                 f32x4 az = {0.f, 0.f, 0.f, 0.f}, ar = {0.f, 0.f, 0.f, 0.f};
                 if (o < H) { az = ld4(bz + o); ar = ld4(br + o); }
                 mfma_tile2<(TPW < 4 ? 4 : 2)>(az, ar, Pz + (int64_t)ot * KG * 64, Pr + (int64_t)ot * KG * 64, bufA, KG, lane);
+                asm volatile("s_nop 0" :: "v"(az.x), "v"(ar.x));
+                TICK(2);
                 if (o < H) {
                     f32x4 z, r;
                     z.x = sigmoidf_(az.x); z.y = sigmoidf_(az.y); z.z = sigmoidf_(az.z); z.w = sigmoidf_(az.w);
@@ -274,7 +284,9 @@ __global__ void __launch_bounds__(GNW * 64) gru_fwd_kernel(const float* __restri
                 }
             }
         }
+        TICK(3);
         lds_barrier();
+        TICK(4);
         // ---- phase 2: n, h' ---------------------------------------------------------------------------------
 #pragma unroll
         for (int i = 0; i < TPW; ++i) {
@@ -284,6 +296,8 @@ __global__ void __launch_bounds__(GNW * 64) gru_fwd_kernel(const float* __restri
                 f32x4 an = {0.f, 0.f, 0.f, 0.f};
                 if (o < H) an = ld4(bn + o);
                 mfma_tile<(TPW < 4 ? 4 : 2)>(an, Pn + (int64_t)ot * KG * 64, bufB, KG, lane);
+                asm volatile("s_nop 0" :: "v"(an.x));
+                TICK(5);
                 if (o < H) {
                     f32x4 n;
                     n.x = tanhf_(an.x); n.y = tanhf_(an.y); n.z = tanhf_(an.z); n.w = tanhf_(an.w);
@@ -299,8 +313,11 @@ __global__ void __launch_bounds__(GNW * 64) gru_fwd_kernel(const float* __restri
                 }
             }
         }
+        TICK(6);
         lds_barrier();  // bufB's x rows are rewritten at the top of the next step
+        TICK(7);
     }
+    if (dbg) for (int i = 0; i < 8; ++i) k8_dbg[i] = acc_[i];
 }
 
 template <int TPW, bool PRE>
