@@ -44,8 +44,8 @@ EXPORTS = {
     "dpk_philox_normal": (c_int, [c_void_p, c_int64, c_uint64, c_uint64, c_float, c_void_p]),
     "dpk_gru_pack_floats": (c_int64, [c_int, c_int]),
     "dpk_gru_pack": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p]),
-    "dpk_gru_forward": (c_int, [c_void_p] * 13 + [c_int, c_int, c_int, c_void_p]),
-    "dpk_gru_backward": (c_int, [c_void_p] * 16 + [c_int, c_int, c_int, c_void_p]),
+    "dpk_gru_forward": (c_int, [c_void_p] * 13 + [c_int, c_int, c_int, c_int, c_void_p]),
+    "dpk_gru_backward": (c_int, [c_void_p] * 16 + [c_int, c_int, c_int, c_int, c_void_p]),
 }
 
 
@@ -254,9 +254,15 @@ def philox_normal(out: torch.Tensor, seed: int, offset: int, std: float):
 
 
 # ---- K8: fused Linear-cell GRU recurrence -------------------------------------------------------------------------
+# Every tensor carries a leading [G] dimension: G independent GRUs of equal shape run in one launch.
 
 
-def gru_pack(src: torch.Tensor, O: int, K: int, transposed: bool, coff: int = 0) -> torch.Tensor:
+def gru_pack_floats(O: int, K: int) -> int:
+    return int(load().dpk_gru_pack_floats(O, K))
+
+
+def gru_pack(src: torch.Tensor, O: int, K: int, transposed: bool, coff: int = 0,
+             out: Optional[torch.Tensor] = None) -> torch.Tensor:
     """Pack W(out,k) of a row-major 2-D weight into MFMA fragment order (see include/dpk.h, K8)."""
     _req(src, "weight")
     if src.dim() != 2 or src.stride(1) != 1:
@@ -265,64 +271,70 @@ def gru_pack(src: torch.Tensor, O: int, K: int, transposed: bool, coff: int = 0)
     need_rows, need_cols = (K, coff + O) if transposed else (O, coff + K)
     if rows < need_rows or cols < need_cols:
         raise DpkError(f"gru_pack: weight {tuple(src.shape)} too small for O={O}, K={K}, coff={coff}")
-    dst = torch.empty(load().dpk_gru_pack_floats(O, K), device=src.device, dtype=torch.float32)
-    rc = load().dpk_gru_pack(_ptr(src), src.stride(0), coff, O, K, int(transposed), _ptr(dst), _stream())
+    n = gru_pack_floats(O, K)
+    if out is None:
+        out = torch.empty(n, device=src.device, dtype=torch.float32)
+    else:
+        _req(out, "packed")
+        if out.numel() != n or not out.is_contiguous():
+            raise DpkError("gru_pack: destination has the wrong size")
+    rc = load().dpk_gru_pack(_ptr(src), src.stride(0), coff, O, K, int(transposed), _ptr(out), _stream())
     _check(rc, "dpk_gru_pack")
-    return dst
+    return out
 
 
 def _gru_shapes(x, name):
     _req(x, name)
-    if x.dim() != 3 or not x.is_contiguous():
-        raise DpkError(f"{name} must be contiguous [B,T,H]")
-    return x.shape
+    if x.dim() != 4 or not x.is_contiguous():
+        raise DpkError(f"{name} must be contiguous [G,B,T,H]")
+    return tuple(x.shape)
 
 
 def gru_forward(xp, h0, Pz, Pr, Pn, bz, br, bn):
-    """Returns out, Z, R, N, RH (all [B,T,H])."""
-    B, T, H = _gru_shapes(xp, "xp")
-    if B == 0 or T == 0:
+    """xp [G,B,T,H]; packed weights [G,n]; biases [G,H]; h0 [G,B,H] or None.  Returns out, Z, R, N, RH [G,B,T,H]."""
+    G, B, T, H = _gru_shapes(xp, "xp")
+    if G == 0 or B == 0 or T == 0:
         raise DpkError("gru_forward: empty batch / sequence")
-    n_pack = load().dpk_gru_pack_floats(H, 2 * H)
+    n_pack = gru_pack_floats(H, 2 * H)
     for t, n in ((Pz, "Pz"), (Pr, "Pr"), (Pn, "Pn")):
         _req(t, n)
-        if t.numel() != n_pack:
-            raise DpkError(f"gru_forward: {n} is not a packed [H,2H] gate weight")
+        if tuple(t.shape) != (G, n_pack) or not t.is_contiguous():
+            raise DpkError(f"gru_forward: {n} is not [G, packed(H,2H)]")
     for t, n in ((bz, "bz"), (br, "br"), (bn, "bn")):
         _req(t, n)
-        if t.numel() != H or not t.is_contiguous():
-            raise DpkError(f"gru_forward: {n} must hold H floats")
+        if tuple(t.shape) != (G, H) or not t.is_contiguous():
+            raise DpkError(f"gru_forward: {n} must be contiguous [G,H]")
     if h0 is not None:
         _req(h0, "h0")
-        if tuple(h0.shape) != (B, H) or not h0.is_contiguous():
-            raise DpkError("gru_forward: h0 must be contiguous [B,H]")
+        if tuple(h0.shape) != (G, B, H) or not h0.is_contiguous():
+            raise DpkError("gru_forward: h0 must be contiguous [G,B,H]")
     outs = [torch.empty_like(xp) for _ in range(5)]
     rc = load().dpk_gru_forward(_ptr(xp), _ptr(h0), _ptr(Pz), _ptr(Pr), _ptr(Pn), _ptr(bz), _ptr(br), _ptr(bn),
-                                *[_ptr(o) for o in outs], B, T, H, _stream())
+                                *[_ptr(o) for o in outs], B, T, H, G, _stream())
     _check(rc, "dpk_gru_forward")
     return outs
 
 
 def gru_backward(dout, dhT, Z, R, N, hall, h0, Pnx, Pnh, Pzrx, Pzrh, want_dh0: bool):
-    """Returns dxp, Gz, Gr, Gn ([B,T,H]) and dh0 ([B,H] or None)."""
-    B, T, H = _gru_shapes(dout, "dout")
+    """Returns dxp, Gz, Gr, Gn ([G,B,T,H]) and dh0 ([G,B,H] or None)."""
+    G, B, T, H = _gru_shapes(dout, "dout")
     for t, n in ((Z, "Z"), (R, "R"), (N, "N"), (hall, "out")):
-        if _gru_shapes(t, n) != (B, T, H):
+        if _gru_shapes(t, n) != (G, B, T, H):
             raise DpkError(f"gru_backward: {n} does not match dout")
-    n1, n2 = load().dpk_gru_pack_floats(H, H), load().dpk_gru_pack_floats(H, 2 * H)
+    n1, n2 = gru_pack_floats(H, H), gru_pack_floats(H, 2 * H)
     for t, n, cnt in ((Pnx, "Pnx", n1), (Pnh, "Pnh", n1), (Pzrx, "Pzrx", n2), (Pzrh, "Pzrh", n2)):
         _req(t, n)
-        if t.numel() != cnt:
+        if tuple(t.shape) != (G, cnt) or not t.is_contiguous():
             raise DpkError(f"gru_backward: {n} has the wrong packed size")
     for t, n in ((dhT, "dhT"), (h0, "h0")):
         if t is not None:
             _req(t, n)
-            if tuple(t.shape) != (B, H) or not t.is_contiguous():
-                raise DpkError(f"gru_backward: {n} must be contiguous [B,H]")
+            if tuple(t.shape) != (G, B, H) or not t.is_contiguous():
+                raise DpkError(f"gru_backward: {n} must be contiguous [G,B,H]")
     outs = [torch.empty_like(dout) for _ in range(4)]
-    dh0 = torch.empty(B, H, device=dout.device, dtype=torch.float32) if want_dh0 else None
+    dh0 = torch.empty(G, B, H, device=dout.device, dtype=torch.float32) if want_dh0 else None
     rc = load().dpk_gru_backward(_ptr(dout), _ptr(dhT), _ptr(Z), _ptr(R), _ptr(N), _ptr(hall), _ptr(h0), _ptr(Pnx),
-                                 _ptr(Pnh), _ptr(Pzrx), _ptr(Pzrh), *[_ptr(o) for o in outs], _ptr(dh0), B, T, H,
+                                 _ptr(Pnh), _ptr(Pzrx), _ptr(Pzrh), *[_ptr(o) for o in outs], _ptr(dh0), B, T, H, G,
                                  _stream())
     _check(rc, "dpk_gru_backward")
     return outs + [dh0]

@@ -28,55 +28,77 @@ def fusable_hidden(h: int) -> bool:
     return h % 8 == 0 and 8 <= h <= MAX_HIDDEN
 
 
+def _stack(ts):
+    return ts[0].unsqueeze(0).contiguous() if len(ts) == 1 else torch.stack(ts, dim=0)
+
+
 class _Recurrence(torch.autograd.Function):
-    @staticmethod
-    def forward(ctx, xp, h0, wz, bz, wr, br, wn, bn, owner, feed):
-        H = xp.shape[-1]
-        xp = xp.contiguous()
-        h0c = None if h0 is None else h0.contiguous()
-        pz = _native.gru_pack(wz, H, 2 * H, False)
-        pr = _native.gru_pack(wr, H, 2 * H, False)
-        pn = _native.gru_pack(wn, H, 2 * H, False)
-        out, Z, R, N, RH = _native.gru_forward(xp, h0c, pz, pr, pn, bz.contiguous(), br.contiguous(), bn.contiguous())
-        ctx.owner = owner
-        ctx.feed = feed
-        ctx.has_h0 = h0 is not None
-        ctx.save_for_backward(xp, h0c, wz, wr, wn, out, Z, R, N, RH)
-        return out
+    """G independent GRUs of equal shape in one launch each way.  Tensor arguments, per GRU g:
+    xp_g, h0_g (or None for all), Wz_g, bz_g, Wr_g, br_g, Wn_g, bn_g;  returns out_0 .. out_{G-1}."""
 
     @staticmethod
-    def backward(ctx, dout):
-        xp, h0, wz, wr, wn, out, Z, R, N, RH = ctx.saved_tensors
-        B, T, H = xp.shape
-        wzr = torch.cat([wz, wr], dim=0)
-        pnx = _native.gru_pack(wn, H, H, True, 0)
-        pnh = _native.gru_pack(wn, H, H, True, H)
-        pzrx = _native.gru_pack(wzr, H, 2 * H, True, 0)
-        pzrh = _native.gru_pack(wzr, H, 2 * H, True, H)
-        want_dh0 = ctx.has_h0 and ctx.needs_input_grad[1]
-        dxp, Gz, Gr, Gn, dh0 = _native.gru_backward(dout.contiguous(), None, Z, R, N, out, h0, pnx, pnh, pzrx, pzrh,
-                                                    want_dh0)
-        owner = ctx.owner
-        need_w = any(ctx.needs_input_grad[2:8])
-        sink = owner._dpk_sink
-        feed = ctx.feed and sink is not None
-        grads = [None] * 6
-        if feed or need_w:
-            first = h0.unsqueeze(1) if h0 is not None else out.new_zeros(B, 1, H)
-            hprev = torch.cat([first, out[:, :-1]], dim=1) if T > 1 else first
-            a_zr = torch.cat([xp, hprev], dim=2)
-            a_n = torch.cat([xp, RH], dim=2)
-            if feed:
-                sink(owner.update_gate, a_zr, Gz)
-                sink(owner.reset_gate, a_zr, Gr)
-                sink(owner.new_gate, a_n, Gn)
-            if need_w:
-                for k, (a, g) in enumerate(((a_zr, Gz), (a_zr, Gr), (a_n, Gn))):
-                    if ctx.needs_input_grad[2 + 2 * k]:
-                        grads[2 * k] = torch.einsum("bto,bti->oi", g, a)
-                    if ctx.needs_input_grad[3 + 2 * k]:
-                        grads[2 * k + 1] = g.sum(dim=(0, 1))
-        return (dxp, dh0, *grads, None, None)
+    def forward(ctx, owners, feed, *args):
+        G = len(owners)
+        per = [args[8 * g:8 * g + 8] for g in range(G)]
+        xp = _stack([p[0] for p in per])
+        _, B, T, H = xp.shape
+        has_h0 = per[0][1] is not None
+        h0 = _stack([p[1] for p in per]) if has_h0 else None
+        n_pack = _native.gru_pack_floats(H, 2 * H)
+        packs = [torch.empty(G, n_pack, device=xp.device, dtype=torch.float32) for _ in range(3)]
+        for g, p in enumerate(per):
+            for k in range(3):
+                _native.gru_pack(p[2 + 2 * k], H, 2 * H, False, out=packs[k][g])
+        biases = [_stack([p[3 + 2 * k] for p in per]) for k in range(3)]
+        out, Z, R, N, RH = _native.gru_forward(xp, h0, *packs, *biases)
+        ctx.owners, ctx.feed, ctx.has_h0 = owners, feed, has_h0
+        ctx.save_for_backward(xp, h0, out, Z, R, N, RH, *[p[2 + 2 * k] for p in per for k in range(3)])
+        return tuple(out[g] for g in range(G))
+
+    @staticmethod
+    def backward(ctx, *douts):
+        xp, h0, out, Z, R, N, RH, *ws = ctx.saved_tensors
+        G, B, T, H = xp.shape
+        owners = ctx.owners
+        n1, n2 = _native.gru_pack_floats(H, H), _native.gru_pack_floats(H, 2 * H)
+        dev = xp.device
+        pnx, pnh = (torch.empty(G, n1, device=dev, dtype=torch.float32) for _ in range(2))
+        pzrx, pzrh = (torch.empty(G, n2, device=dev, dtype=torch.float32) for _ in range(2))
+        for g in range(G):
+            wz, wr, wn = ws[3 * g:3 * g + 3]
+            wzr = torch.cat([wz, wr], dim=0)
+            _native.gru_pack(wn, H, H, True, 0, out=pnx[g])
+            _native.gru_pack(wn, H, H, True, H, out=pnh[g])
+            _native.gru_pack(wzr, H, 2 * H, True, 0, out=pzrx[g])
+            _native.gru_pack(wzr, H, 2 * H, True, H, out=pzrh[g])
+        dout = _stack([d if d is not None else torch.zeros_like(out[0]) for d in douts])
+        need = ctx.needs_input_grad[2:]
+        want_dh0 = ctx.has_h0 and any(need[8 * g + 1] for g in range(G))
+        dxp, Gz, Gr, Gn, dh0 = _native.gru_backward(dout, None, Z, R, N, out, h0, pnx, pnh, pzrx, pzrh, want_dh0)
+        grads = []
+        for g in range(G):
+            owner = owners[g]
+            need_w = any(need[8 * g + 2:8 * g + 8])
+            sink = owner._dpk_sink
+            feed = ctx.feed and sink is not None
+            gw = [None] * 6
+            if feed or need_w:
+                first = h0[g].unsqueeze(1) if h0 is not None else out.new_zeros(B, 1, H)
+                hprev = torch.cat([first, out[g, :, :-1]], dim=1) if T > 1 else first
+                a_zr = torch.cat([xp[g], hprev], dim=2)
+                a_n = torch.cat([xp[g], RH[g]], dim=2)
+                if feed:
+                    sink(owner.update_gate, a_zr, Gz[g])
+                    sink(owner.reset_gate, a_zr, Gr[g])
+                    sink(owner.new_gate, a_n, Gn[g])
+                if need_w:
+                    for k, (a, gg) in enumerate(((a_zr, Gz[g]), (a_zr, Gr[g]), (a_n, Gn[g]))):
+                        if need[8 * g + 2 + 2 * k]:
+                            gw[2 * k] = torch.einsum("bto,bti->oi", gg, a)
+                        if need[8 * g + 3 + 2 * k]:
+                            gw[2 * k + 1] = gg.sum(dim=(0, 1))
+            grads += [dxp[g], dh0[g] if (dh0 is not None and need[8 * g + 1]) else None, *gw]
+        return (None, None, *grads)
 
 
 class FusedLinearCellGRU(nn.Module):
@@ -139,18 +161,20 @@ class FusedLinearCellGRU(nn.Module):
         out = torch.stack(outs, dim=1) if outs else x.new_zeros(B, 0, self.hidden_size)
         return out, h.unsqueeze(0)
 
-    def forward(self, x, h=None):
-        if not self.batch_first:
-            x = x.transpose(0, 1)
-        B, T, _ = x.shape
-        fused = (x.is_cuda and x.dtype == torch.float32 and B > 0 and T > 0 and fusable_hidden(self.hidden_size)
-                 and self.update_gate.bias is not None)
-        if not fused:
-            return self._forward_loop(x, h)
+    def _fusable_call(self, x, h) -> bool:
+        return (x.dim() == 3 and x.is_cuda and x.dtype == torch.float32 and x.shape[0] > 0 and x.shape[1] > 0
+                and fusable_hidden(self.hidden_size) and self.update_gate.bias is not None
+                and (h is None or (h.dim() == 2 and h.is_cuda and h.dtype == torch.float32)))
+
+    def _dp_active(self) -> bool:
+        return (self._dpk_sink is not None and self.training and torch.is_grad_enabled()
+                and (self._dpk_sink_active is None or self._dpk_sink_active()))
+
+    def _prepare(self, x, h):
+        """input projection + the 8 tensor arguments of this GRU for _Recurrence; also whether the DP sink is on."""
         xp = self.input_layer(x)
         gates = (self.update_gate, self.reset_gate, self.new_gate)
-        dp = (self._dpk_sink is not None and self.training and torch.is_grad_enabled()
-              and (self._dpk_sink_active is None or self._dpk_sink_active()))
+        dp = self._dp_active()
         if dp:
             # per-sample gradients come from the sink; autograd must not also build the summed ones
             wb = [t.detach() for g in gates for t in (g.weight, g.bias)]
@@ -158,8 +182,37 @@ class FusedLinearCellGRU(nn.Module):
                 raise RuntimeError("FusedLinearCellGRU under DP needs a differentiable input projection")
         else:
             wb = [t for g in gates for t in (g.weight, g.bias)]
-        out = _Recurrence.apply(xp, h, *wb, self, dp)
+        return [xp, h, *wb], dp
+
+    def forward(self, x, h=None):
+        if not self.batch_first:
+            x = x.transpose(0, 1)
+        if not self._fusable_call(x, h):
+            return self._forward_loop(x, h)
+        args, dp = self._prepare(x, h)
+        (out,) = _Recurrence.apply((self,), dp, *args)
         return out, out[:, -1].unsqueeze(0)
+
+
+def run_together(modules, xs, hs=None):
+    """Call several recurrent modules that do not depend on each other (DeapStack_DP's encoder_mu / encoder_logvar,
+    timeautoencoder.py:117-120).  When all are FusedLinearCellGRU of one shape they share ONE forward and ONE
+    backward launch — a recurrence has only B/16 workgroups, so this is what fills the chip; otherwise they are
+    simply called in turn.  Returns [module(x, h) for ...]."""
+    hs = hs if hs is not None else [None] * len(modules)
+    ok = (len(modules) > 1 and all(isinstance(m, FusedLinearCellGRU) and m.batch_first for m in modules)
+          and len({m.hidden_size for m in modules}) == 1
+          and len({tuple(x.shape[:2]) for x in xs}) == 1
+          and (all(h is None for h in hs) or all(h is not None for h in hs))
+          and all(m._fusable_call(x, h) for m, x, h in zip(modules, xs, hs))
+          and len({m._dp_active() for m in modules}) == 1)
+    if not ok:
+        return [m(x, h) if h is not None else m(x) for m, x, h in zip(modules, xs, hs)]
+    args = []
+    for m, x, h in zip(modules, xs, hs):
+        args += m._prepare(x, h)[0]
+    outs = _Recurrence.apply(tuple(modules), modules[0]._dp_active(), *args)
+    return [(o, o[:, -1].unsqueeze(0)) for o in outs]
 
 
 def looks_like_linear_cell_gru(m: nn.Module) -> bool:

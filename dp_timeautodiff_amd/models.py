@@ -19,7 +19,7 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
-from .layers import DPLSTM
+from .layers import DPLSTM, run_together
 
 
 def sine_cosine_features(v: torch.Tensor, num_terms: int = 8) -> torch.Tensor:
@@ -115,8 +115,8 @@ class DeapStackDP(nn.Module):
 
     def encoder(self, x):
         x = self.Emb(x)
-        mu_z, _ = self.encoder_mu(x)
-        logvar_z, _ = self.encoder_logvar(x)
+        # the two encoders read the same x and do not depend on each other: fused ones share one launch
+        (mu_z, _), (logvar_z, _) = run_together([self.encoder_mu, self.encoder_logvar], [x, x])
         mu_z = self.fc_mu(mu_z)
         logvar_z = self.fc_logvar(logvar_z)
         return self.reparametrize(mu_z, logvar_z), mu_z, logvar_z

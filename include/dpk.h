@@ -150,6 +150,10 @@ int dpk_philox_normal(float* out, int64_t n, uint64_t seed, uint64_t offset, flo
  * order by dpk_gru_pack (dpk_gru_pack_floats(O,K) floats per packed matrix):
  *   W(out,k) = transposed ? src[k*ld + coff + out] : src[out*ld + coff + k],  out < O, k < K.
  * H must be a multiple of 8 and at most 512 (DPK_ERANGE otherwise).
+ * One launch runs G independent GRUs of equal shape (e.g. DeapStack_DP's encoder_mu and encoder_logvar,
+ * timeautoencoder.py:117-120, which read the same input): every tensor below, packed weights and biases included,
+ * then carries a leading contiguous [G] dimension.  A recurrence only has B/16 workgroups per GRU, so batching
+ * independent ones is what fills the chip.
  *
  * forward:  Pz/Pr/Pn = pack(W_update / W_reset / W_new, O=H, K=2H).  h0 [B,H] nullable (zeros).
  *   writes out = h_t, Z, R, N (gate activations) and RH = r_t * h_{t-1}, all [B,T,H].
@@ -164,11 +168,11 @@ int64_t dpk_gru_pack_floats(int O, int K);
 int dpk_gru_pack(const float* src, int ld, int coff, int O, int K, int transposed, float* dst, void* stream);
 int dpk_gru_forward(const float* xp, const float* h0, const float* Pz, const float* Pr, const float* Pn,
                     const float* bz, const float* br, const float* bn, float* out, float* Z, float* R,
-                    float* N, float* RH, int B, int T, int H, void* stream);
+                    float* N, float* RH, int B, int T, int H, int G, void* stream);
 int dpk_gru_backward(const float* dout, const float* dhT, const float* Z, const float* R, const float* N,
                      const float* hall, const float* h0, const float* Pnx, const float* Pnh,
                      const float* Pzrx, const float* Pzrh, float* dxp, float* Gz, float* Gr, float* Gn,
-                     float* dh0, int B, int T, int H, void* stream);
+                     float* dh0, int B, int T, int H, int G, void* stream);
 
 #ifdef __cplusplus
 }
