@@ -180,6 +180,19 @@ def _kind_of(m: nn.Module) -> Optional[str]:
     return None
 
 
+class _GradTap(torch.autograd.Function):
+    """Identity that puts `y` into the autograd graph without any upstream work: backward returns nothing, so a
+    layer whose input is data and whose parameters are frozen for autograd costs no dW GEMM and no reduction."""
+
+    @staticmethod
+    def forward(ctx, y, anchor):
+        return y.view_as(y)
+
+    @staticmethod
+    def backward(ctx, g):
+        return None, None
+
+
 class GradSampleModule(nn.Module):
     """Wraps `m`; after backward every trainable parameter has `.grad_sample` ([B, *shape] view)."""
 
@@ -213,6 +226,8 @@ class GradSampleModule(nn.Module):
         if errors and strict:
             raise NotImplementedError(f"Model contains layers without a per-sample-gradient kernel: {errors}")
         self.arena = GradSampleArena(params, device)
+        # anchor of _GradTap (not a parameter: invisible to state_dict / optimizers)
+        object.__setattr__(self, "_tap", torch.zeros((), device=device, requires_grad=True))
 
         covered = set()
         for name, sub in m.named_modules():
@@ -338,8 +353,7 @@ class GradSampleModule(nn.Module):
     def _make_pre(self, layer: _Layer):
         def hook(module, inputs):
             if (self.skip_autograd_param_grads and self.hooks_enabled and module.training
-                    and torch.is_grad_enabled() and layer.kind != "embedding"
-                    and isinstance(inputs[0], torch.Tensor) and inputs[0].requires_grad):
+                    and torch.is_grad_enabled() and isinstance(inputs[0], torch.Tensor)):
                 for p in layer.params:
                     p.requires_grad_(False)
                 layer.frozen_for_autograd = True
@@ -348,16 +362,24 @@ class GradSampleModule(nn.Module):
 
     def _make_fwd(self, layer: _Layer):
         def hook(module, inputs, output):
+            tapped = None
             if layer.frozen_for_autograd:
                 for p in layer.params:
                     p.requires_grad_(True)
                 layer.frozen_for_autograd = False
+                if isinstance(output, torch.Tensor) and not output.requires_grad:
+                    # first layer of the model (its input is data): nothing upstream needs a gradient, but the
+                    # backward hook must still see grad_output -> keep the output in the graph at zero cost
+                    if self._tap.device != output.device:
+                        object.__setattr__(self, "_tap", torch.zeros((), device=output.device, requires_grad=True))
+                    tapped = _GradTap.apply(output, self._tap)
             if not self.hooks_enabled or not module.training or not torch.is_grad_enabled():
-                return
+                return tapped
             layer.acts.append(inputs[0].detach())
             layer.counter += 1
             for p in layer.params:
                 p._forward_counter += 1
+            return tapped
 
         return hook
 

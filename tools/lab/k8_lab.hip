@@ -93,7 +93,7 @@ __device__ __forceinline__ void mfma_tile(f32x4& acc, const f32x4* __restrict__ 
             const BFrag bn = ld_bfrag(p);  // kg + s + 1 < KG here
             __builtin_amdgcn_sched_barrier(0);
             DPK_MFMA4(acc, w[s], bc.b0, bc.b1, bc.b2, bc.b3);
-            w[s] = pw[(kg + s + GPF) * 64];
+            if (K8_WL) w[s] = pw[(kg + s + GPF) * 64];
             __builtin_amdgcn_sched_barrier(0);
             bc = bn;
         }
@@ -146,9 +146,9 @@ __device__ __forceinline__ void mfma_tile2(f32x4& a0, f32x4& a1, const f32x4* __
             const BFrag bn = ld_bfrag(p);
             __builtin_amdgcn_sched_barrier(0);
             DPK_MFMA4(a0, w0[s], bc.b0, bc.b1, bc.b2, bc.b3);
-            w0[s] = pw0[(kg + s + GPF) * 64];
+            if (K8_WL) w0[s] = pw0[(kg + s + GPF) * 64];
             DPK_MFMA4(a1, w1[s], bc.b0, bc.b1, bc.b2, bc.b3);
-            w1[s] = pw1[(kg + s + GPF) * 64];
+            if (K8_WL) w1[s] = pw1[(kg + s + GPF) * 64];
             __builtin_amdgcn_sched_barrier(0);
             bc = bn;
         }
@@ -162,8 +162,8 @@ __device__ __forceinline__ void mfma_tile2(f32x4& a0, f32x4& a1, const f32x4* __
             DPK_MFMA4(a0, w0[s], bc.b0, bc.b1, bc.b2, bc.b3);
             DPK_MFMA4(a1, w1[s], bc.b0, bc.b1, bc.b2, bc.b3);
             if (s + GPF < rem) {
-                w0[s] = pw0[(kg + s + GPF) * 64];
-                w1[s] = pw1[(kg + s + GPF) * 64];
+                if (K8_WL) w0[s] = pw0[(kg + s + GPF) * 64];
+                if (K8_WL) w1[s] = pw1[(kg + s + GPF) * 64];
             }
             p = pn;
             bc = bn;
@@ -200,7 +200,7 @@ __global__ void __launch_bounds__(GNW * 64) gru_fwd_kernel(const float* __restri
                                                            const float* __restrict__ br, const float* __restrict__ bn,
                                                            float* __restrict__ out, float* __restrict__ Z,
                                                            float* __restrict__ R, float* __restrict__ N,
-                                                           float* __restrict__ RH, int B, int T, int H) {
+                                                           float* RH, int B, int T, int H) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     constexpr int NTH = GNW * 64;
     const int KG = (2 * H + 15) / 16;
@@ -214,6 +214,13 @@ __global__ void __launch_bounds__(GNW * 64) gru_fwd_kernel(const float* __restri
     const int b = b0 + j;
     const bool bvalid = b < B;
     const int H4 = H / 4;
+    {   // blockIdx.y = which of the G independent GRUs of this launch (every tensor has a leading [G] dimension)
+        const int64_t g = blockIdx.y, gx = g * B * T * H, gp = g * NT * KG * 64;
+        xp += gx; out += gx; Z += gx; R += gx; N += gx; RH += gx;
+        if (h0) h0 += g * B * H;
+        Pz += gp; Pr += gp; Pn += gp;
+        bz += g * H; br += g * H; bn += g * H;
+    }
     const int nx4 = GBT * H4;  // float4 elements of one x_t tile; <= TPW * NTH by construction of TPW
 
     for (int i = threadIdx.x; i < 2 * K16 * GBT; i += NTH) smem[i] = 0.f;
@@ -341,6 +348,15 @@ __global__ void __launch_bounds__(GNW * 64) gru_bwd_kernel(const float* __restri
     const int j = lane & 15, q = lane >> 4;
     const int b = blockIdx.x * GBT + j;
     const bool bvalid = b < B;
+    {
+        const int64_t g = blockIdx.y, gx = g * B * T * H, gh = g * B * H;
+        dout += gx; Z += gx; R += gx; N += gx; hall += gx; dxp += gx; Gz += gx; Gr += gx; Gn += gx;
+        if (dhT) dhT += gh;
+        if (h0) h0 += gh;
+        if (dh0) dh0 += gh;
+        Pnx += g * NT * KGn * 64; Pnh += g * NT * KGn * 64;
+        Pzrx += g * NT * KGzr * 64; Pzrh += g * NT * KGzr * 64;
+    }
 
     for (int i = threadIdx.x; i < (KGn + KGzr) * 16 * GBT; i += NTH) smem[i] = 0.f;
     __syncthreads();
@@ -471,9 +487,10 @@ extern "C" int dpk_gru_pack(const float* src, int ld, int coff, int O, int K, in
 
 extern "C" int dpk_gru_forward(const float* xp, const float* h0, const float* Pz, const float* Pr, const float* Pn,
                                const float* bz, const float* br, const float* bn, float* out, float* Z, float* R,
-                               float* N, float* RH, int B, int T, int H, void* stream) {
+                               float* N, float* RH, int B, int T, int H, int G, void* stream) {
     if (!xp || !Pz || !Pr || !Pn || !bz || !br || !bn || !out || !Z || !R || !N || !RH) return DPK_EINVAL;
-    if (B <= 0 || T <= 0 || H <= 0) return DPK_EINVAL;
+    if (B <= 0 || T <= 0 || H <= 0 || G <= 0) return DPK_EINVAL;
+    if (G > 65535) return DPK_ERANGE;
     if (H % 8) return DPK_ERANGE;  // 2H must be a whole number of 16-wide K groups; rows are stored 4 at a time
     const int tpw = gru_tpw(H);
     if (!tpw) return DPK_ERANGE;
@@ -482,7 +499,7 @@ extern "C" int dpk_gru_forward(const float* xp, const float* h0, const float* Pz
         if (p && !dpk_aligned16(p)) return DPK_EALIGN;
     const size_t lds = (size_t)2 * ((2 * H + 15) / 16) * 16 * GBT * sizeof(float);
     if (lds > 150 * 1024) return DPK_ERANGE;
-    dim3 grid((unsigned)((B + GBT - 1) / GBT));
+    dim3 grid((unsigned)((B + GBT - 1) / GBT), (unsigned)G);
     hipStream_t s = (hipStream_t)stream;
 #define DPK_GRU_F(TPW)                                                                                              \
     do {                                                                                                            \
@@ -504,11 +521,11 @@ extern "C" int dpk_gru_forward(const float* xp, const float* h0, const float* Pz
 extern "C" int dpk_gru_backward(const float* dout, const float* dhT, const float* Z, const float* R, const float* N,
                                 const float* hall, const float* h0, const float* Pnx, const float* Pnh,
                                 const float* Pzrx, const float* Pzrh, float* dxp, float* Gz, float* Gr, float* Gn,
-                                float* dh0, int B, int T, int H, void* stream) {
+                                float* dh0, int B, int T, int H, int G, void* stream) {
     if (!dout || !Z || !R || !N || !hall || !Pnx || !Pnh || !Pzrx || !Pzrh || !dxp || !Gz || !Gr || !Gn)
         return DPK_EINVAL;
-    if (B <= 0 || T <= 0 || H <= 0) return DPK_EINVAL;
-    if (H % 8) return DPK_ERANGE;
+    if (B <= 0 || T <= 0 || H <= 0 || G <= 0) return DPK_EINVAL;
+    if (H % 8 || G > 65535) return DPK_ERANGE;
     const int tpw = gru_tpw(H);
     if (!tpw) return DPK_ERANGE;
     const void* ptrs[] = {dout, dhT, Z, R, N, hall, h0, Pnx, Pnh, Pzrx, Pzrh, dxp, Gz, Gr, Gn, dh0};
@@ -516,7 +533,7 @@ extern "C" int dpk_gru_backward(const float* dout, const float* dhT, const float
         if (p && !dpk_aligned16(p)) return DPK_EALIGN;
     const size_t lds = (size_t)(((H + 15) / 16) + ((2 * H + 15) / 16)) * 16 * GBT * sizeof(float);
     if (lds > 150 * 1024) return DPK_ERANGE;
-    dim3 grid((unsigned)((B + GBT - 1) / GBT));
+    dim3 grid((unsigned)((B + GBT - 1) / GBT), (unsigned)G);
     hipStream_t s = (hipStream_t)stream;
 #define DPK_GRU_B(TPW)                                                                                              \
     do {                                                                                                            \
