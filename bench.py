@@ -227,7 +227,7 @@ def main():
         "config": {"workload": f"{args.config}: {workloads.CONFIGS[args.config]['desc']}",
                    "per_gpu_batch": B, "global_batch": B * world, "physical_batch": phys,
                    "params": wl.n_params, "parallelism": f"dp{world}",
-                   "step": "zero_grad+forward+backward(hooks: K1/K3/K4)+DPOptimizer.step(K6,K7)+Adam",
+                   "step": "zero_grad+forward(K8)+backward(K8; per-sample grads K1/K3/K4)+DPOptimizer.step(K6,K7)+Adam(K9)",
                    "gru": "hooked T-step loop" if args.hooked_gru else "fused K8 recurrence",
                    "launch": ("hipGraph replay of the captured step" + (" (local part; all-reduce+noise+Adam eager)"
                               if world > 1 else "")) if graphed is not None else "eager"},

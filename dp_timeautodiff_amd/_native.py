@@ -42,6 +42,7 @@ EXPORTS = {
                                       c_void_p, c_float, c_float, c_void_p, c_void_p, c_int, c_int64, c_void_p, c_int64,
                                       c_void_p]),
     "dpk_philox_normal": (c_int, [c_void_p, c_int64, c_uint64, c_uint64, c_float, c_void_p]),
+    "dpk_adam_step": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_int64, c_void_p]),
     "dpk_gru_pack_floats": (c_int64, [c_int, c_int]),
     "dpk_gru_pack": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p]),
     "dpk_gru_forward": (c_int, [c_void_p] * 13 + [c_int, c_int, c_int, c_int, c_void_p]),
@@ -338,3 +339,23 @@ def gru_backward(dout, dhT, Z, R, N, hall, h0, Pnx, Pnh, Pzrx, Pzrh, want_dh0: b
                                  _stream())
     _check(rc, "dpk_gru_backward")
     return outs + [dh0]
+
+
+# ---- K9: Adam on the arena-layout gradient ------------------------------------------------------------------------
+
+
+def adam_step(grad, exp_avg, exp_avg_sq, win_table, hyper, step_dev, P: int):
+    for t, n in ((grad, "grad"), (exp_avg, "exp_avg"), (exp_avg_sq, "exp_avg_sq"), (hyper, "hyper"),
+                 (step_dev, "step")):
+        _req(t, n)
+    _req(win_table, "win_table", torch.int64)
+    n = win_table.shape[0]
+    if win_table.dim() != 2 or win_table.shape[1] != 5 or tuple(hyper.shape) != (n, 8) or n == 0:
+        raise DpkError("adam_step: tables must be [n,5] int64 and [n,8] float32")
+    if not (win_table.is_contiguous() and hyper.is_contiguous()):
+        raise DpkError("adam_step: tables must be contiguous")
+    if min(grad.numel(), exp_avg.numel(), exp_avg_sq.numel()) < P or step_dev.numel() != 1:
+        raise DpkError("adam_step: vectors shorter than P")
+    rc = load().dpk_adam_step(_ptr(grad), _ptr(exp_avg), _ptr(exp_avg_sq), _ptr(win_table), _ptr(hyper), n,
+                              _ptr(step_dev), P, _stream())
+    _check(rc, "dpk_adam_step")

@@ -28,7 +28,7 @@ from typing import Callable, List, Optional
 import torch
 from torch.optim import Optimizer
 
-from . import _native
+from . import _native, fused_adam
 
 
 def _generate_seed() -> int:
@@ -38,9 +38,12 @@ def _generate_seed() -> int:
 class DPOptimizer(Optimizer):
     def __init__(self, optimizer: Optimizer, *, noise_multiplier: float, max_grad_norm: float,
                  expected_batch_size: Optional[int], loss_reduction: str = "mean", generator=None,
-                 secure_mode: bool = False, noise_seed: Optional[int] = None, **kwargs):
+                 secure_mode: bool = False, noise_seed: Optional[int] = None, fused_inner_step: bool = True,
+                 **kwargs):
         if loss_reduction not in ("mean", "sum"):
             raise ValueError(f"Unexpected value for loss_reduction: {loss_reduction}")
+        self.fused_inner_step = fused_inner_step  # plain torch.optim.Adam -> one K9 launch on the arena gradient
+        self._fused_adam = None
         if loss_reduction == "mean" and expected_batch_size is None:
             raise ValueError("You must provide expected batch size of the loss reduction is mean")
         self.original_optimizer = optimizer
@@ -246,12 +249,21 @@ class DPOptimizer(Optimizer):
         self._is_last_step_skipped = False
         return True
 
+    def _inner_step(self):
+        """The wrapped optimizer's update on p.grad (= views of arena.grad)."""
+        if self.fused_inner_step and self._fused_adam is None and self.arena.device.type == "cuda" \
+                and fused_adam.supported(self.original_optimizer):
+            self._fused_adam = fused_adam.FusedAdam(self.original_optimizer, self.arena)
+        if self._fused_adam is not None and self.fused_inner_step:
+            return self._fused_adam.step()
+        return self.original_optimizer.step()
+
     def step(self, closure: Optional[Callable[[], float]] = None) -> Optional[float]:
         if closure is not None:
             with torch.enable_grad():
                 closure()
         if self.pre_step():
-            return self.original_optimizer.step()
+            return self._inner_step()
         return None
 
     def zero_grad(self, set_to_none: bool = False):
@@ -283,10 +295,14 @@ class DPOptimizer(Optimizer):
         return self.original_optimizer.__repr__()
 
     def state_dict(self):
+        if self._fused_adam is not None:
+            return self._fused_adam.dense_state_dict()
         return self.original_optimizer.state_dict()
 
     def load_state_dict(self, state_dict) -> None:
         self.original_optimizer.load_state_dict(state_dict)
+        if self._fused_adam is not None:
+            self._fused_adam.reload()
 
 
 class DistributedDPOptimizer(DPOptimizer):
@@ -360,7 +376,7 @@ class DistributedDPOptimizer(DPOptimizer):
         if self.step_hook:
             self.step_hook(self)
         self._is_last_step_skipped = False
-        return self.original_optimizer.step()
+        return self._inner_step()
 
     def add_noise(self):
         raise NotImplementedError("use step(): the distributed path all-reduces between sum and noise")

@@ -174,6 +174,20 @@ int dpk_gru_backward(const float* dout, const float* dhT, const float* Z, const 
                      const float* Pzrx, const float* Pzrh, float* dxp, float* Gz, float* Gr, float* Gn,
                      float* dh0, int B, int T, int H, int G, void* stream);
 
+/*
+ * K9 — Adam with L2 weight decay on the arena-layout gradient.  Replaces
+ * torch.optim.Adam.step() as called by DPOptimizer.step() (optimizer built at timeautoencoder.py:658, stepped at
+ * :751) with one launch:  g = grad + wd*p;  m += (g-m)(1-b1);  v = b2 v + (1-b2) g^2;
+ * p -= lr/(1-b1^t) * m / (sqrt(v)/sqrt(1-b2^t) + eps),  t = *step_dev + 1  (the caller then advances *step_dev).
+ * grad / exp_avg / exp_avg_sq are [P] vectors laid out like an arena row.  win_table: n_windows rows of 5 int64
+ * {param device pointer (dense row-major [rows,cols]), arena offset, rows, cols, ld}, ordered by offset, offsets
+ * multiples of 4, ld a multiple of 4 wherever ld != cols.  hyper: n_windows rows of 8 floats
+ * {lr, beta1, beta2, eps, weight_decay, 1-beta1, 1-beta2, 0} (the complements rounded from double, as torch
+ * passes them).  Both tables live in device memory.
+ */
+int dpk_adam_step(const float* grad, float* exp_avg, float* exp_avg_sq, const int64_t* win_table,
+                  const float* hyper, int n_windows, const float* step_dev, int64_t P, void* stream);
+
 #ifdef __cplusplus
 }
 #endif
