@@ -44,9 +44,11 @@ EXPORTS = {
     "dpk_philox_normal": (c_int, [c_void_p, c_int64, c_uint64, c_uint64, c_float, c_void_p]),
     "dpk_adam_step": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_int64, c_void_p]),
     "dpk_gru_pack_floats": (c_int64, [c_int, c_int]),
-    "dpk_gru_pack": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p]),
-    "dpk_gru_forward": (c_int, [c_void_p] * 13 + [c_int, c_int, c_int, c_int, c_void_p]),
-    "dpk_gru_backward": (c_int, [c_void_p] * 16 + [c_int, c_int, c_int, c_int, c_void_p]),
+    "dpk_gru_pack_forward": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p]),
+    "dpk_gru_pack_backward": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int,
+                                      c_void_p]),
+    "dpk_gru_forward": (c_int, [c_void_p] * 12 + [c_int, c_int, c_int, c_int, c_void_p]),
+    "dpk_gru_backward": (c_int, [c_void_p] * 15 + [c_int, c_int, c_int, c_int, c_void_p]),
 }
 
 
@@ -255,90 +257,117 @@ def philox_normal(out: torch.Tensor, seed: int, offset: int, std: float):
 
 
 # ---- K8: fused Linear-cell GRU recurrence -------------------------------------------------------------------------
-# Every tensor carries a leading [G] dimension: G independent GRUs of equal shape run in one launch.
+# Per-GRU inputs travel as host arrays of device pointers; outputs and packed weights carry a leading [G] dimension.
+
+GRU_MAX_G = 8
 
 
 def gru_pack_floats(O: int, K: int) -> int:
     return int(load().dpk_gru_pack_floats(O, K))
 
 
-def gru_pack(src: torch.Tensor, O: int, K: int, transposed: bool, coff: int = 0,
-             out: Optional[torch.Tensor] = None) -> torch.Tensor:
-    """Pack W(out,k) of a row-major 2-D weight into MFMA fragment order (see include/dpk.h, K8)."""
-    _req(src, "weight")
-    if src.dim() != 2 or src.stride(1) != 1:
-        raise DpkError("gru_pack: weight must be a row-major 2-D tensor")
-    rows, cols = src.shape
-    need_rows, need_cols = (K, coff + O) if transposed else (O, coff + K)
-    if rows < need_rows or cols < need_cols:
-        raise DpkError(f"gru_pack: weight {tuple(src.shape)} too small for O={O}, K={K}, coff={coff}")
-    n = gru_pack_floats(O, K)
-    if out is None:
-        out = torch.empty(n, device=src.device, dtype=torch.float32)
-    else:
-        _req(out, "packed")
-        if out.numel() != n or not out.is_contiguous():
-            raise DpkError("gru_pack: destination has the wrong size")
-    rc = load().dpk_gru_pack(_ptr(src), src.stride(0), coff, O, K, int(transposed), _ptr(out), _stream())
-    _check(rc, "dpk_gru_pack")
-    return out
+def _ptr_array(tensors, name, shape=None, allow_none=False):
+    arr = (c_void_p * len(tensors))()
+    for i, t in enumerate(tensors):
+        if t is None:
+            if not allow_none:
+                raise DpkError(f"{name}[{i}] is None")
+            arr[i] = None
+            continue
+        _req(t, f"{name}[{i}]")
+        if not t.is_contiguous() or (shape is not None and tuple(t.shape) != tuple(shape)):
+            raise DpkError(f"{name}[{i}] must be contiguous {tuple(shape) if shape else ''}, got {tuple(t.shape)}")
+        arr[i] = t.data_ptr()
+    return arr
 
 
-def _gru_shapes(x, name):
-    _req(x, name)
-    if x.dim() != 4 or not x.is_contiguous():
-        raise DpkError(f"{name} must be contiguous [G,B,T,H]")
-    return tuple(x.shape)
+def _gru_weights(weights, H):
+    """weights: 3 per GRU (update, reset, new), each nn.Linear(2H, H).weight -> pointer array, G, device."""
+    if len(weights) == 0 or len(weights) % 3:
+        raise DpkError("gru_pack: expected 3 weights (update, reset, new) per GRU")
+    G = len(weights) // 3
+    if G > GRU_MAX_G:
+        raise DpkError(f"at most {GRU_MAX_G} GRUs per launch")
+    return _ptr_array(weights, "W", (H, 2 * H)), G, weights[0].device
 
 
-def gru_forward(xp, h0, Pz, Pr, Pn, bz, br, bn):
-    """xp [G,B,T,H]; packed weights [G,n]; biases [G,H]; h0 [G,B,H] or None.  Returns out, Z, R, N, RH [G,B,T,H]."""
-    G, B, T, H = _gru_shapes(xp, "xp")
-    if G == 0 or B == 0 or T == 0:
+def gru_pack_forward(weights, H: int):
+    arr, G, dev = _gru_weights(weights, H)
+    n = gru_pack_floats(H, 2 * H)
+    Pz, Pr, Pn = (torch.empty(G, n, device=dev, dtype=torch.float32) for _ in range(3))
+    _check(load().dpk_gru_pack_forward(arr, 2 * H, _ptr(Pz), _ptr(Pr), _ptr(Pn), H, G, _stream()),
+           "dpk_gru_pack_forward")
+    return Pz, Pr, Pn
+
+
+def gru_pack_backward(weights, H: int):
+    arr, G, dev = _gru_weights(weights, H)
+    n1, n2 = gru_pack_floats(H, H), gru_pack_floats(H, 2 * H)
+    Pnx, Pnh = (torch.empty(G, n1, device=dev, dtype=torch.float32) for _ in range(2))
+    Pzrx, Pzrh = (torch.empty(G, n2, device=dev, dtype=torch.float32) for _ in range(2))
+    _check(load().dpk_gru_pack_backward(arr, 2 * H, _ptr(Pnx), _ptr(Pnh), _ptr(Pzrx), _ptr(Pzrh), H, G, _stream()),
+           "dpk_gru_pack_backward")
+    return Pnx, Pnh, Pzrx, Pzrh
+
+
+def gru_forward(xps, h0s, Pz, Pr, Pn, biases):
+    """xps: G tensors [B,T,H]; h0s: None or G tensors [B,H]; biases: 3 per GRU [H].
+    Returns out, Z, R, N [G,B,T,H] and the stacked gate inputs Azr, An [G,B,T,2H]."""
+    G = len(xps)
+    if G == 0 or G > GRU_MAX_G or len(biases) != 3 * G or (h0s is not None and len(h0s) != G):
+        raise DpkError("gru_forward: inconsistent number of GRUs")
+    _req(xps[0], "xp[0]")
+    if xps[0].dim() != 3:
+        raise DpkError("gru_forward: xp must be [B,T,H]")
+    B, T, H = xps[0].shape
+    if B == 0 or T == 0:
         raise DpkError("gru_forward: empty batch / sequence")
+    xa = _ptr_array(xps, "xp", (B, T, H))
+    ha = None if h0s is None else _ptr_array(h0s, "h0", (B, H))
+    ba = _ptr_array(biases, "bias", (H,))
     n_pack = gru_pack_floats(H, 2 * H)
     for t, n in ((Pz, "Pz"), (Pr, "Pr"), (Pn, "Pn")):
         _req(t, n)
         if tuple(t.shape) != (G, n_pack) or not t.is_contiguous():
             raise DpkError(f"gru_forward: {n} is not [G, packed(H,2H)]")
-    for t, n in ((bz, "bz"), (br, "br"), (bn, "bn")):
-        _req(t, n)
-        if tuple(t.shape) != (G, H) or not t.is_contiguous():
-            raise DpkError(f"gru_forward: {n} must be contiguous [G,H]")
-    if h0 is not None:
-        _req(h0, "h0")
-        if tuple(h0.shape) != (G, B, H) or not h0.is_contiguous():
-            raise DpkError("gru_forward: h0 must be contiguous [G,B,H]")
-    outs = [torch.empty_like(xp) for _ in range(5)]
-    rc = load().dpk_gru_forward(_ptr(xp), _ptr(h0), _ptr(Pz), _ptr(Pr), _ptr(Pn), _ptr(bz), _ptr(br), _ptr(bn),
-                                *[_ptr(o) for o in outs], B, T, H, G, _stream())
+    dev = xps[0].device
+    out, Z, R, N = (torch.empty(G, B, T, H, device=dev, dtype=torch.float32) for _ in range(4))
+    Azr, An = (torch.empty(G, B, T, 2 * H, device=dev, dtype=torch.float32) for _ in range(2))
+    rc = load().dpk_gru_forward(xa, ha, _ptr(Pz), _ptr(Pr), _ptr(Pn), ba, _ptr(out), _ptr(Z), _ptr(R), _ptr(N),
+                                _ptr(Azr), _ptr(An), B, T, H, G, _stream())
     _check(rc, "dpk_gru_forward")
-    return outs
+    return out, Z, R, N, Azr, An
 
 
-def gru_backward(dout, dhT, Z, R, N, hall, h0, Pnx, Pnh, Pzrx, Pzrh, want_dh0: bool):
-    """Returns dxp, Gz, Gr, Gn ([G,B,T,H]) and dh0 ([G,B,H] or None)."""
-    G, B, T, H = _gru_shapes(dout, "dout")
-    for t, n in ((Z, "Z"), (R, "R"), (N, "N"), (hall, "out")):
-        if _gru_shapes(t, n) != (G, B, T, H):
-            raise DpkError(f"gru_backward: {n} does not match dout")
+def gru_backward(douts, dhTs, Z, R, N, Azr, Pnx, Pnh, Pzrx, Pzrh, want_dh0: bool):
+    """douts: G tensors [B,T,H] (None entries = zeros).  Returns dxp, Gz, Gr, Gn [G,B,T,H], dh0 [G,B,H] or None."""
+    _req(Z, "Z")
+    if Z.dim() != 4 or not Z.is_contiguous():
+        raise DpkError("gru_backward: Z must be contiguous [G,B,T,H]")
+    G, B, T, H = Z.shape
+    if len(douts) != G or (dhTs is not None and len(dhTs) != G):
+        raise DpkError("gru_backward: inconsistent number of GRUs")
+    for t, n in ((R, "R"), (N, "N")):
+        _req(t, n)
+        if tuple(t.shape) != (G, B, T, H) or not t.is_contiguous():
+            raise DpkError(f"gru_backward: {n} does not match Z")
+    _req(Azr, "Azr")
+    if tuple(Azr.shape) != (G, B, T, 2 * H) or not Azr.is_contiguous():
+        raise DpkError("gru_backward: Azr must be contiguous [G,B,T,2H]")
     n1, n2 = gru_pack_floats(H, H), gru_pack_floats(H, 2 * H)
     for t, n, cnt in ((Pnx, "Pnx", n1), (Pnh, "Pnh", n1), (Pzrx, "Pzrx", n2), (Pzrh, "Pzrh", n2)):
         _req(t, n)
         if tuple(t.shape) != (G, cnt) or not t.is_contiguous():
             raise DpkError(f"gru_backward: {n} has the wrong packed size")
-    for t, n in ((dhT, "dhT"), (h0, "h0")):
-        if t is not None:
-            _req(t, n)
-            if tuple(t.shape) != (G, B, H) or not t.is_contiguous():
-                raise DpkError(f"gru_backward: {n} must be contiguous [G,B,H]")
-    outs = [torch.empty_like(dout) for _ in range(4)]
-    dh0 = torch.empty(G, B, H, device=dout.device, dtype=torch.float32) if want_dh0 else None
-    rc = load().dpk_gru_backward(_ptr(dout), _ptr(dhT), _ptr(Z), _ptr(R), _ptr(N), _ptr(hall), _ptr(h0), _ptr(Pnx),
-                                 _ptr(Pnh), _ptr(Pzrx), _ptr(Pzrh), *[_ptr(o) for o in outs], _ptr(dh0), B, T, H, G,
+    da = _ptr_array(douts, "dout", (B, T, H), allow_none=True)
+    ha = None if dhTs is None else _ptr_array(dhTs, "dhT", (B, H), allow_none=True)
+    dxp, Gz, Gr, Gn = (torch.empty_like(Z) for _ in range(4))
+    dh0 = torch.empty(G, B, H, device=Z.device, dtype=torch.float32) if want_dh0 else None
+    rc = load().dpk_gru_backward(da, ha, _ptr(Z), _ptr(R), _ptr(N), _ptr(Azr), _ptr(Pnx), _ptr(Pnh), _ptr(Pzrx),
+                                 _ptr(Pzrh), _ptr(dxp), _ptr(Gz), _ptr(Gr), _ptr(Gn), _ptr(dh0), B, T, H, G,
                                  _stream())
     _check(rc, "dpk_gru_backward")
-    return outs + [dh0]
+    return dxp, Gz, Gr, Gn, dh0
 
 
 # ---- K9: Adam on the arena-layout gradient ------------------------------------------------------------------------

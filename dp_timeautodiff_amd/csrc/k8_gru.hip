@@ -34,10 +34,30 @@ __device__ __forceinline__ float tanhf_(float x) { return 1.0f - 2.0f * __frcp_r
 // global stores issued just before it (~1 us each time step); nothing here communicates through global memory.
 __device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
-// dst[((ot*KG + kg)*64 + l)*4 + m] = W(out = ot*16 + (l&15), k = kg*16 + m*4 + (l>>4)), zero outside O x K.
-// W(out,k) = transposed ? src[k*ld + coff + out] : src[out*ld + coff + k]
-__global__ void __launch_bounds__(256) gru_pack_kernel(const float* __restrict__ src, int ld, int coff, int O, int K,
-                                                       int transposed, float* __restrict__ dst, int OT, int KG) {
+constexpr int GNW = 8;  // waves per workgroup (2 per SIMD: one wave's weight loads hide behind the other's MFMAs)
+constexpr int GMAX = DPK_GRU_MAX_G;  // GRUs per launch: pointer tables travel by value in the kernel arguments
+struct GPtrs { const float* p[GMAX]; };
+struct GPtrs3 { const float* p[3 * GMAX]; };
+
+// One launch packs every weight matrix of a call.  Job y: dst[((ot*KG + kg)*64 + l)*4 + m] = W(out, k) with
+// out = ot*16 + (l&15), k = kg*16 + m*4 + (l>>4), zero outside H x K, where
+//   W(out,k) = !transposed ? src[out*ld + k] : (k < H ? src[k*ld + coff + out] : src2[(k-H)*ld + coff + out])
+struct PackJobs {
+    const float* src[4 * GMAX];
+    const float* src2[4 * GMAX];
+    float* dst[4 * GMAX];
+    int coff[4 * GMAX];
+    int K[4 * GMAX];
+    int transposed[4 * GMAX];
+};
+
+__global__ void __launch_bounds__(256) gru_pack_kernel(PackJobs jobs, int ld, int H) {
+    const int y = blockIdx.y;
+    const float* __restrict__ src = jobs.src[y];
+    const float* __restrict__ src2 = jobs.src2[y];
+    float* __restrict__ dst = jobs.dst[y];
+    const int coff = jobs.coff[y], K = jobs.K[y], transposed = jobs.transposed[y];
+    const int OT = (H + 15) / 16, KG = (K + 15) / 16;
     const int64_t n = (int64_t)OT * KG * 256;
     for (int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x; idx < n; idx += (int64_t)gridDim.x * 256) {
         const int m = (int)(idx & 3);
@@ -48,12 +68,13 @@ __global__ void __launch_bounds__(256) gru_pack_kernel(const float* __restrict__
         const int o = ot * 16 + (l & 15);
         const int k = kg * 16 + m * 4 + (l >> 4);
         float v = 0.f;
-        if (o < O && k < K) v = transposed ? src[(int64_t)k * ld + coff + o] : src[(int64_t)o * ld + coff + k];
+        if (o < H && k < K) {
+            if (!transposed) v = src[(int64_t)o * ld + k];
+            else v = k < H ? src[(int64_t)k * ld + coff + o] : src2[(int64_t)(k - H) * ld + coff + o];
+        }
         dst[idx] = v;
     }
 }
-
-constexpr int GNW = 8;   // waves per workgroup (2 per SIMD: one wave's weight loads hide behind the other's MFMAs)
 
 // acc += W-tile x LDS operand, K in groups of 16 (4 MFMAs per 16-byte weight load).  A ring of GPF weight groups is
 // kept in flight (L2 latency ~ 3 groups of MFMA issue); the main loop is branch-free so that every ring slot stays in
@@ -191,13 +212,12 @@ __device__ __forceinline__ void lds_col4(float* s, int o, int j, f32x4 v) {
 }
 
 template <int TPW, bool PRE>
-__global__ void __launch_bounds__(GNW * 64) gru_fwd_kernel(const float* __restrict__ xp, const float* __restrict__ h0,
-                                                           const f32x4* __restrict__ Pz, const f32x4* __restrict__ Pr,
-                                                           const f32x4* __restrict__ Pn, const float* __restrict__ bz,
-                                                           const float* __restrict__ br, const float* __restrict__ bn,
-                                                           float* __restrict__ out, float* __restrict__ Z,
-                                                           float* __restrict__ R, float* __restrict__ N,
-                                                           float* RH, int B, int T, int H) {
+__global__ void __launch_bounds__(GNW * 64) gru_fwd_kernel(GPtrs xps, GPtrs h0s, const f32x4* __restrict__ Pz,
+                                                           const f32x4* __restrict__ Pr, const f32x4* __restrict__ Pn,
+                                                           GPtrs3 biases, float* __restrict__ out,
+                                                           float* __restrict__ Z, float* __restrict__ R,
+                                                           float* __restrict__ N, float* __restrict__ Azr,
+                                                           float* __restrict__ An, int B, int T, int H) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     constexpr int NTH = GNW * 64;
     const int KG = (2 * H + 15) / 16;
@@ -211,12 +231,17 @@ __global__ void __launch_bounds__(GNW * 64) gru_fwd_kernel(const float* __restri
     const int b = b0 + j;
     const bool bvalid = b < B;
     const int H4 = H / 4;
-    {   // blockIdx.y = which of the G independent GRUs of this launch (every tensor has a leading [G] dimension)
-        const int64_t g = blockIdx.y, gx = g * B * T * H, gp = g * NT * KG * 64;
-        xp += gx; out += gx; Z += gx; R += gx; N += gx; RH += gx;
-        if (h0) h0 += g * B * H;
+    // blockIdx.y = which of the G independent GRUs of this launch: inputs come through per-GRU pointers, everything
+    // this kernel writes (and the packed weights) has a leading [G] dimension
+    const int gi = blockIdx.y;
+    const float* __restrict__ xp = xps.p[gi];
+    const float* __restrict__ h0 = h0s.p[gi];
+    const float* __restrict__ bz = biases.p[3 * gi], * __restrict__ br = biases.p[3 * gi + 1],
+                             * __restrict__ bn = biases.p[3 * gi + 2];
+    {
+        const int64_t g = gi, gx = g * B * T * H, gp = g * NT * KG * 64;
+        out += gx; Z += gx; R += gx; N += gx; Azr += 2 * gx; An += 2 * gx;
         Pz += gp; Pr += gp; Pn += gp;
-        bz += g * H; br += g * H; bn += g * H;
     }
     const int nx4 = GBT * H4;  // float4 elements of one x_t tile; <= TPW * NTH by construction of TPW
 
@@ -252,6 +277,11 @@ __global__ void __launch_bounds__(GNW * 64) gru_fwd_kernel(const float* __restri
             if (idx < nx4) {
                 lds_col4(bufA, k4 * 4, jj, xpre[i]);
                 lds_col4(bufB, k4 * 4, jj, xpre[i]);
+                if (b0 + jj < B) {  // x half of the gates' stacked activations [x_t | h_{t-1}] and [x_t | r*h_{t-1}]
+                    const int64_t ga = ((int64_t)(b0 + jj) * T + t) * 2 * H + k4 * 4;
+                    st4(Azr + ga, xpre[i]);
+                    st4(An + ga, xpre[i]);
+                }
             }
         }
         lds_barrier();
@@ -276,7 +306,9 @@ __global__ void __launch_bounds__(GNW * 64) gru_fwd_kernel(const float* __restri
                         const int64_t g = ((int64_t)b * T + t) * H + o;
                         st4(Z + g, z);
                         st4(R + g, r);
-                        st4(RH + g, rh);
+                        const int64_t ga = ((int64_t)b * T + t) * 2 * H + H + o;
+                        st4(Azr + ga, hreg[i]);
+                        st4(An + ga, rh);
                     }
                 }
             }
@@ -311,10 +343,9 @@ __global__ void __launch_bounds__(GNW * 64) gru_fwd_kernel(const float* __restri
 }
 
 template <int TPW, bool PRE>
-__global__ void __launch_bounds__(GNW * 64) gru_bwd_kernel(const float* __restrict__ dout, const float* __restrict__ dhT,
-                                                           const float* __restrict__ Z, const float* __restrict__ R,
-                                                           const float* __restrict__ N, const float* __restrict__ hall,
-                                                           const float* __restrict__ h0, const f32x4* __restrict__ Pnx,
+__global__ void __launch_bounds__(GNW * 64) gru_bwd_kernel(GPtrs douts, GPtrs dhTs, const float* __restrict__ Z,
+                                                           const float* __restrict__ R, const float* __restrict__ N,
+                                                           const float* __restrict__ Azr, const f32x4* __restrict__ Pnx,
                                                            const f32x4* __restrict__ Pnh, const f32x4* __restrict__ Pzrx,
                                                            const f32x4* __restrict__ Pzrh, float* __restrict__ dxp,
                                                            float* __restrict__ Gz, float* __restrict__ Gr,
@@ -331,11 +362,11 @@ __global__ void __launch_bounds__(GNW * 64) gru_bwd_kernel(const float* __restri
     const int j = lane & 15, q = lane >> 4;
     const int b = blockIdx.x * GBT + j;
     const bool bvalid = b < B;
+    const float* __restrict__ dout = douts.p[blockIdx.y];  // null: no gradient reached this GRU's output
+    const float* __restrict__ dhT = dhTs.p[blockIdx.y];
     {
         const int64_t g = blockIdx.y, gx = g * B * T * H, gh = g * B * H;
-        dout += gx; Z += gx; R += gx; N += gx; hall += gx; dxp += gx; Gz += gx; Gr += gx; Gn += gx;
-        if (dhT) dhT += gh;
-        if (h0) h0 += gh;
+        Z += gx; R += gx; N += gx; Azr += 2 * gx; dxp += gx; Gz += gx; Gr += gx; Gn += gx;
         if (dh0) dh0 += gh;
         Pnx += g * NT * KGn * 64; Pnh += g * NT * KGn * 64;
         Pzrx += g * NT * KGzr * 64; Pzrh += g * NT * KGzr * 64;
@@ -355,12 +386,11 @@ __global__ void __launch_bounds__(GNW * 64) gru_bwd_kernel(const float* __restri
             p_do[i] = p_z[i] = p_n[i] = p_r[i] = p_hp[i] = zero4;
             if (ot < NT && o < H && bvalid) {
                 const int64_t g = ((int64_t)b * T + t) * H + o;
-                p_do[i] = ld4(dout + g);
+                if (dout) p_do[i] = ld4(dout + g);
                 p_z[i] = ld4(Z + g);
                 p_n[i] = ld4(N + g);
                 p_r[i] = ld4(R + g);
-                if (t > 0) p_hp[i] = ld4(hall + g - H);
-                else if (h0) p_hp[i] = ld4(h0 + (int64_t)b * H + o);
+                p_hp[i] = ld4(Azr + ((int64_t)b * T + t) * 2 * H + H + o);  // h_{t-1} as the forward stacked it
             }
         }
     };
@@ -455,31 +485,91 @@ extern "C" int64_t dpk_gru_pack_floats(int O, int K) {
     return (int64_t)((O + 15) / 16) * ((K + 15) / 16) * 256;
 }
 
-extern "C" int dpk_gru_pack(const float* src, int ld, int coff, int O, int K, int transposed, float* dst,
-                            void* stream) {
-    if (!src || !dst || O <= 0 || K <= 0 || ld <= 0 || coff < 0) return DPK_EINVAL;
-    if (!dpk_aligned16(dst)) return DPK_EALIGN;
-    const int OT = (O + 15) / 16, KG = (K + 15) / 16;
-    const int64_t n = (int64_t)OT * KG * 256;
+static int gru_check_shape(int B, int T, int H, int G) {
+    if (B <= 0 || T <= 0 || H <= 0 || G <= 0) return DPK_EINVAL;
+    if (G > GMAX) return DPK_ERANGE;
+    if (H % 8) return DPK_ERANGE;  // 2H must be a whole number of 16-wide K groups; rows are stored 4 at a time
+    if (!gru_tpw(H)) return DPK_ERANGE;
+    return DPK_OK;
+}
+
+static int gru_launch_pack(const PackJobs& jobs, int njobs, int ld, int H, hipStream_t s) {
+    const int64_t n = dpk_gru_pack_floats(H, 2 * H);
     int64_t blocks = (n + 255) / 256;
-    if (blocks > 4096) blocks = 4096;
-    hipLaunchKernelGGL(gru_pack_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, src, ld, coff, O, K,
-                       transposed, dst, OT, KG);
+    if (blocks > 1024) blocks = 1024;
+    hipLaunchKernelGGL(gru_pack_kernel, dim3((unsigned)blocks, (unsigned)njobs), dim3(256), 0, s, jobs, ld, H);
     return dpk_launch_status();
 }
 
-extern "C" int dpk_gru_forward(const float* xp, const float* h0, const float* Pz, const float* Pr, const float* Pn,
-                               const float* bz, const float* br, const float* bn, float* out, float* Z, float* R,
-                               float* N, float* RH, int B, int T, int H, int G, void* stream) {
-    if (!xp || !Pz || !Pr || !Pn || !bz || !br || !bn || !out || !Z || !R || !N || !RH) return DPK_EINVAL;
-    if (B <= 0 || T <= 0 || H <= 0 || G <= 0) return DPK_EINVAL;
-    if (G > 65535) return DPK_ERANGE;
-    if (H % 8) return DPK_ERANGE;  // 2H must be a whole number of 16-wide K groups; rows are stored 4 at a time
-    const int tpw = gru_tpw(H);
-    if (!tpw) return DPK_ERANGE;
-    const void* ptrs[] = {xp, h0, Pz, Pr, Pn, bz, br, bn, out, Z, R, N, RH};
+extern "C" int dpk_gru_pack_forward(const float* const* W, int ld, float* Pz, float* Pr, float* Pn, int H, int G,
+                                    void* stream) {
+    if (!W || !Pz || !Pr || !Pn || H <= 0 || G <= 0 || ld < 2 * H) return DPK_EINVAL;
+    if (G > GMAX) return DPK_ERANGE;
+    if (!dpk_aligned16(Pz) || !dpk_aligned16(Pr) || !dpk_aligned16(Pn)) return DPK_EALIGN;
+    const int64_t n = dpk_gru_pack_floats(H, 2 * H);
+    PackJobs jobs{};
+    float* dst[3] = {Pz, Pr, Pn};
+    for (int g = 0; g < G; ++g)
+        for (int k = 0; k < 3; ++k) {
+            const int y = g * 3 + k;
+            if (!W[y]) return DPK_EINVAL;
+            jobs.src[y] = W[y];
+            jobs.src2[y] = W[y];
+            jobs.dst[y] = dst[k] + g * n;
+            jobs.coff[y] = 0;
+            jobs.K[y] = 2 * H;
+            jobs.transposed[y] = 0;
+        }
+    return gru_launch_pack(jobs, 3 * G, ld, H, (hipStream_t)stream);
+}
+
+extern "C" int dpk_gru_pack_backward(const float* const* W, int ld, float* Pnx, float* Pnh, float* Pzrx, float* Pzrh,
+                                     int H, int G, void* stream) {
+    if (!W || !Pnx || !Pnh || !Pzrx || !Pzrh || H <= 0 || G <= 0 || ld < 2 * H) return DPK_EINVAL;
+    if (G > GMAX) return DPK_ERANGE;
+    if (!dpk_aligned16(Pnx) || !dpk_aligned16(Pnh) || !dpk_aligned16(Pzrx) || !dpk_aligned16(Pzrh)) return DPK_EALIGN;
+    const int64_t n1 = dpk_gru_pack_floats(H, H), n2 = dpk_gru_pack_floats(H, 2 * H);
+    PackJobs jobs{};
+    for (int g = 0; g < G; ++g) {
+        const float *wz = W[3 * g], *wr = W[3 * g + 1], *wn = W[3 * g + 2];
+        if (!wz || !wr || !wn) return DPK_EINVAL;
+        const float* src[4] = {wn, wn, wz, wz};
+        const float* src2[4] = {wn, wn, wr, wr};
+        float* dst[4] = {Pnx + g * n1, Pnh + g * n1, Pzrx + g * n2, Pzrh + g * n2};
+        const int coff[4] = {0, H, 0, H}, K[4] = {H, H, 2 * H, 2 * H};
+        for (int k = 0; k < 4; ++k) {
+            const int y = g * 4 + k;
+            jobs.src[y] = src[k];
+            jobs.src2[y] = src2[k];
+            jobs.dst[y] = dst[k];
+            jobs.coff[y] = coff[k];
+            jobs.K[y] = K[k];
+            jobs.transposed[y] = 1;
+        }
+    }
+    return gru_launch_pack(jobs, 4 * G, ld, H, (hipStream_t)stream);
+}
+
+extern "C" int dpk_gru_forward(const float* const* xp, const float* const* h0, const float* Pz, const float* Pr,
+                               const float* Pn, const float* const* bias, float* out, float* Z, float* R, float* N,
+                               float* Azr, float* An, int B, int T, int H, int G, void* stream) {
+    if (!xp || !Pz || !Pr || !Pn || !bias || !out || !Z || !R || !N || !Azr || !An) return DPK_EINVAL;
+    if (int rc = gru_check_shape(B, T, H, G)) return rc;
+    const void* ptrs[] = {Pz, Pr, Pn, out, Z, R, N, Azr, An};
     for (const void* p : ptrs)
-        if (p && !dpk_aligned16(p)) return DPK_EALIGN;
+        if (!dpk_aligned16(p)) return DPK_EALIGN;
+    GPtrs xps{}, h0s{};
+    GPtrs3 bs{};
+    for (int g = 0; g < G; ++g) {
+        if (!xp[g] || !bias[3 * g] || !bias[3 * g + 1] || !bias[3 * g + 2]) return DPK_EINVAL;
+        xps.p[g] = xp[g];
+        h0s.p[g] = h0 ? h0[g] : nullptr;
+        for (int k = 0; k < 3; ++k) bs.p[3 * g + k] = bias[3 * g + k];
+        if (!dpk_aligned16(xps.p[g]) || !dpk_aligned16(h0s.p[g]) || !dpk_aligned16(bs.p[3 * g]) ||
+            !dpk_aligned16(bs.p[3 * g + 1]) || !dpk_aligned16(bs.p[3 * g + 2]))
+            return DPK_EALIGN;
+    }
+    const int tpw = gru_tpw(H);
     const size_t lds = (size_t)2 * ((2 * H + 15) / 16) * 16 * GBT * sizeof(float);
     if (lds > 150 * 1024) return DPK_ERANGE;
     dim3 grid((unsigned)((B + GBT - 1) / GBT), (unsigned)G);
@@ -487,12 +577,13 @@ extern "C" int dpk_gru_forward(const float* xp, const float* h0, const float* Pz
 #define DPK_GRU_F(TPW)                                                                                              \
     do {                                                                                                            \
         if (lds > 64 * 1024) {                                                                                      \
-            hipError_t e_ = hipFuncSetAttribute((const void*)gru_fwd_kernel<TPW, (TPW < 4)>,                                   \
+            hipError_t e_ = hipFuncSetAttribute((const void*)gru_fwd_kernel<TPW, (TPW < 4)>,                        \
                                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);              \
             if (e_ != hipSuccess) return (int)e_;                                                                   \
         }                                                                                                           \
-        hipLaunchKernelGGL((gru_fwd_kernel<TPW, (TPW < 4)>), grid, dim3(GNW * 64), lds, s, xp, h0, (const f32x4*)Pz,                \
-                           (const f32x4*)Pr, (const f32x4*)Pn, bz, br, bn, out, Z, R, N, RH, B, T, H);              \
+        hipLaunchKernelGGL((gru_fwd_kernel<TPW, (TPW < 4)>), grid, dim3(GNW * 64), lds, s, xps, h0s,                \
+                           (const f32x4*)Pz, (const f32x4*)Pr, (const f32x4*)Pn, bs, out, Z, R, N, Azr, An, B, T,  \
+                           H);                                                                                      \
     } while (0)
     if (tpw == 1) DPK_GRU_F(1);
     else if (tpw == 2) DPK_GRU_F(2);
@@ -501,19 +592,23 @@ extern "C" int dpk_gru_forward(const float* xp, const float* h0, const float* Pz
     return dpk_launch_status();
 }
 
-extern "C" int dpk_gru_backward(const float* dout, const float* dhT, const float* Z, const float* R, const float* N,
-                                const float* hall, const float* h0, const float* Pnx, const float* Pnh,
+extern "C" int dpk_gru_backward(const float* const* dout, const float* const* dhT, const float* Z, const float* R,
+                                const float* N, const float* Azr, const float* Pnx, const float* Pnh,
                                 const float* Pzrx, const float* Pzrh, float* dxp, float* Gz, float* Gr, float* Gn,
                                 float* dh0, int B, int T, int H, int G, void* stream) {
-    if (!dout || !Z || !R || !N || !hall || !Pnx || !Pnh || !Pzrx || !Pzrh || !dxp || !Gz || !Gr || !Gn)
+    if (!dout || !Z || !R || !N || !Azr || !Pnx || !Pnh || !Pzrx || !Pzrh || !dxp || !Gz || !Gr || !Gn)
         return DPK_EINVAL;
-    if (B <= 0 || T <= 0 || H <= 0 || G <= 0) return DPK_EINVAL;
-    if (H % 8 || G > 65535) return DPK_ERANGE;
-    const int tpw = gru_tpw(H);
-    if (!tpw) return DPK_ERANGE;
-    const void* ptrs[] = {dout, dhT, Z, R, N, hall, h0, Pnx, Pnh, Pzrx, Pzrh, dxp, Gz, Gr, Gn, dh0};
+    if (int rc = gru_check_shape(B, T, H, G)) return rc;
+    const void* ptrs[] = {Z, R, N, Azr, Pnx, Pnh, Pzrx, Pzrh, dxp, Gz, Gr, Gn, dh0};
     for (const void* p : ptrs)
         if (p && !dpk_aligned16(p)) return DPK_EALIGN;
+    GPtrs ds{}, hs{};
+    for (int g = 0; g < G; ++g) {
+        ds.p[g] = dout[g];
+        hs.p[g] = dhT ? dhT[g] : nullptr;
+        if (!dpk_aligned16(ds.p[g]) || !dpk_aligned16(hs.p[g])) return DPK_EALIGN;
+    }
+    const int tpw = gru_tpw(H);
     const size_t lds = (size_t)(((H + 15) / 16) + ((2 * H + 15) / 16)) * 16 * GBT * sizeof(float);
     if (lds > 150 * 1024) return DPK_ERANGE;
     dim3 grid((unsigned)((B + GBT - 1) / GBT), (unsigned)G);
@@ -521,11 +616,11 @@ extern "C" int dpk_gru_backward(const float* dout, const float* dhT, const float
 #define DPK_GRU_B(TPW)                                                                                              \
     do {                                                                                                            \
         if (lds > 64 * 1024) {                                                                                      \
-            hipError_t e_ = hipFuncSetAttribute((const void*)gru_bwd_kernel<TPW, (TPW < 4)>,                                   \
+            hipError_t e_ = hipFuncSetAttribute((const void*)gru_bwd_kernel<TPW, (TPW < 4)>,                        \
                                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);              \
             if (e_ != hipSuccess) return (int)e_;                                                                   \
         }                                                                                                           \
-        hipLaunchKernelGGL((gru_bwd_kernel<TPW, (TPW < 4)>), grid, dim3(GNW * 64), lds, s, dout, dhT, Z, R, N, hall, h0,            \
+        hipLaunchKernelGGL((gru_bwd_kernel<TPW, (TPW < 4)>), grid, dim3(GNW * 64), lds, s, ds, hs, Z, R, N, Azr,    \
                            (const f32x4*)Pnx, (const f32x4*)Pnh, (const f32x4*)Pzrx, (const f32x4*)Pzrh, dxp, Gz,  \
                            Gr, Gn, dh0, B, T, H);                                                                   \
     } while (0)

@@ -28,10 +28,6 @@ def fusable_hidden(h: int) -> bool:
     return h % 8 == 0 and 8 <= h <= MAX_HIDDEN
 
 
-def _stack(ts):
-    return ts[0].unsqueeze(0).contiguous() if len(ts) == 1 else torch.stack(ts, dim=0)
-
-
 class _Recurrence(torch.autograd.Function):
     """G independent GRUs of equal shape in one launch each way.  Tensor arguments, per GRU g:
     xp_g, h0_g (or None for all), Wz_g, bz_g, Wr_g, br_g, Wn_g, bn_g;  returns out_0 .. out_{G-1}."""
@@ -40,63 +36,42 @@ class _Recurrence(torch.autograd.Function):
     def forward(ctx, owners, feed, *args):
         G = len(owners)
         per = [args[8 * g:8 * g + 8] for g in range(G)]
-        xp = _stack([p[0] for p in per])
-        _, B, T, H = xp.shape
+        xps = [p[0].contiguous() for p in per]
+        H = xps[0].shape[-1]
         has_h0 = per[0][1] is not None
-        h0 = _stack([p[1] for p in per]) if has_h0 else None
-        n_pack = _native.gru_pack_floats(H, 2 * H)
-        packs = [torch.empty(G, n_pack, device=xp.device, dtype=torch.float32) for _ in range(3)]
-        for g, p in enumerate(per):
-            for k in range(3):
-                _native.gru_pack(p[2 + 2 * k], H, 2 * H, False, out=packs[k][g])
-        biases = [_stack([p[3 + 2 * k] for p in per]) for k in range(3)]
-        out, Z, R, N, RH = _native.gru_forward(xp, h0, *packs, *biases)
+        h0s = [p[1].contiguous() for p in per] if has_h0 else None
+        weights = [p[2 + 2 * k].contiguous() for p in per for k in range(3)]
+        biases = [p[3 + 2 * k].contiguous() for p in per for k in range(3)]
+        packs = _native.gru_pack_forward(weights, H)
+        out, Z, R, N, Azr, An = _native.gru_forward(xps, h0s, *packs, biases)
         ctx.owners, ctx.feed, ctx.has_h0 = owners, feed, has_h0
-        ctx.save_for_backward(xp, h0, out, Z, R, N, RH, *[p[2 + 2 * k] for p in per for k in range(3)])
+        ctx.save_for_backward(Z, R, N, Azr, An, *weights)
         return tuple(out[g] for g in range(G))
 
     @staticmethod
     def backward(ctx, *douts):
-        xp, h0, out, Z, R, N, RH, *ws = ctx.saved_tensors
-        G, B, T, H = xp.shape
+        Z, R, N, Azr, An, *weights = ctx.saved_tensors
+        G, B, T, H = Z.shape
         owners = ctx.owners
-        n1, n2 = _native.gru_pack_floats(H, H), _native.gru_pack_floats(H, 2 * H)
-        dev = xp.device
-        pnx, pnh = (torch.empty(G, n1, device=dev, dtype=torch.float32) for _ in range(2))
-        pzrx, pzrh = (torch.empty(G, n2, device=dev, dtype=torch.float32) for _ in range(2))
-        for g in range(G):
-            wz, wr, wn = ws[3 * g:3 * g + 3]
-            wzr = torch.cat([wz, wr], dim=0)
-            _native.gru_pack(wn, H, H, True, 0, out=pnx[g])
-            _native.gru_pack(wn, H, H, True, H, out=pnh[g])
-            _native.gru_pack(wzr, H, 2 * H, True, 0, out=pzrx[g])
-            _native.gru_pack(wzr, H, 2 * H, True, H, out=pzrh[g])
-        dout = _stack([d if d is not None else torch.zeros_like(out[0]) for d in douts])
+        packs = _native.gru_pack_backward(weights, H)
         need = ctx.needs_input_grad[2:]
         want_dh0 = ctx.has_h0 and any(need[8 * g + 1] for g in range(G))
-        dxp, Gz, Gr, Gn, dh0 = _native.gru_backward(dout, None, Z, R, N, out, h0, pnx, pnh, pzrx, pzrh, want_dh0)
+        douts = [None if d is None else d.contiguous() for d in douts]
+        dxp, Gz, Gr, Gn, dh0 = _native.gru_backward(douts, None, Z, R, N, Azr, *packs, want_dh0)
         grads = []
         for g in range(G):
             owner = owners[g]
-            need_w = any(need[8 * g + 2:8 * g + 8])
             sink = owner._dpk_sink
-            feed = ctx.feed and sink is not None
+            if ctx.feed and sink is not None:  # per-sample gradients: K1 straight from the kernels' buffers
+                sink(owner.update_gate, Azr[g], Gz[g])
+                sink(owner.reset_gate, Azr[g], Gr[g])
+                sink(owner.new_gate, An[g], Gn[g])
             gw = [None] * 6
-            if feed or need_w:
-                first = h0[g].unsqueeze(1) if h0 is not None else out.new_zeros(B, 1, H)
-                hprev = torch.cat([first, out[g, :, :-1]], dim=1) if T > 1 else first
-                a_zr = torch.cat([xp[g], hprev], dim=2)
-                a_n = torch.cat([xp[g], RH[g]], dim=2)
-                if feed:
-                    sink(owner.update_gate, a_zr, Gz[g])
-                    sink(owner.reset_gate, a_zr, Gr[g])
-                    sink(owner.new_gate, a_n, Gn[g])
-                if need_w:
-                    for k, (a, gg) in enumerate(((a_zr, Gz[g]), (a_zr, Gr[g]), (a_n, Gn[g]))):
-                        if need[8 * g + 2 + 2 * k]:
-                            gw[2 * k] = torch.einsum("bto,bti->oi", gg, a)
-                        if need[8 * g + 3 + 2 * k]:
-                            gw[2 * k + 1] = gg.sum(dim=(0, 1))
+            for k, (a, gg) in enumerate(((Azr[g], Gz[g]), (Azr[g], Gr[g]), (An[g], Gn[g]))):
+                if need[8 * g + 2 + 2 * k]:
+                    gw[2 * k] = torch.einsum("bto,bti->oi", gg, a)
+                if need[8 * g + 3 + 2 * k]:
+                    gw[2 * k + 1] = gg.sum(dim=(0, 1))
             grads += [dxp[g], dh0[g] if (dh0 is not None and need[8 * g + 1]) else None, *gw]
         return (None, None, *grads)
 

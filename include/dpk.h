@@ -146,31 +146,38 @@ int dpk_philox_normal(float* out, int64_t n, uint64_t seed, uint64_t offset, flo
  * K8 — fused Linear-cell GRU recurrence: the caller either side of K1.  Replaces the T-step
  * Python loop of CustomGRU.forward (Model_Code/timeautoencoder.py:74-96: cat -> update_gate/reset_gate ->
  * cat -> new_gate -> blend, per time step) and its autograd backward with ONE launch each.  x has already been
- * through input_layer (xp [B,T,H]).  Gate weights are nn.Linear(2H, H) weights, pre-packed into MFMA fragment
- * order by dpk_gru_pack (dpk_gru_pack_floats(O,K) floats per packed matrix):
- *   W(out,k) = transposed ? src[k*ld + coff + out] : src[out*ld + coff + k],  out < O, k < K.
- * H must be a multiple of 8 and at most 512 (DPK_ERANGE otherwise).
- * One launch runs G independent GRUs of equal shape (e.g. DeapStack_DP's encoder_mu and encoder_logvar,
- * timeautoencoder.py:117-120, which read the same input): every tensor below, packed weights and biases included,
- * then carries a leading contiguous [G] dimension.  A recurrence only has B/16 workgroups per GRU, so batching
- * independent ones is what fills the chip.
+ * through input_layer (xp [B,T,H]).  H must be a multiple of 8 and at most 512 (DPK_ERANGE otherwise).
  *
- * forward:  Pz/Pr/Pn = pack(W_update / W_reset / W_new, O=H, K=2H).  h0 [B,H] nullable (zeros).
- *   writes out = h_t, Z, R, N (gate activations) and RH = r_t * h_{t-1}, all [B,T,H].
- * backward: dout [B,T,H] = dL/dout; dhT [B,H] nullable = dL/dh_T on top of dout[:,T-1];
- *   Pnx  = pack(W_new,            transposed, coff=0, O=H, K=H)     Pnh  = same with coff=H
- *   Pzrx = pack([W_update;W_reset], transposed, coff=0, O=H, K=2H)  Pzrh = same with coff=H
- *   writes dxp [B,T,H] and the gates' pre-activation gradients Gz, Gr, Gn [B,T,H] — the stacked backprops that
- *   dpk_linear_grad_sample contracts (K = T) with A_zr = [xp | h_{t-1}] (update, reset) and A_n = [xp | RH] (new);
- *   dh0 [B,H] nullable.
+ * One launch runs G <= DPK_GRU_MAX_G independent GRUs of equal shape (e.g. DeapStack_DP's encoder_mu and
+ * encoder_logvar, timeautoencoder.py:117-120, which read the same input): a recurrence has only B/16 workgroups
+ * per GRU, so batching independent ones is what fills the chip.  Per-GRU INPUTS arrive as host arrays of device
+ * pointers (`const float* const*`, read during the call; the tensors may live anywhere); everything the kernels
+ * WRITE, and the packed weights, are single buffers with a leading contiguous [G] dimension.
+ *
+ * Gate weights are nn.Linear(2H, H) weights ([H, 2H] row-major, row stride ld), given as W[3g+0..2] =
+ * {update, reset, new} of GRU g and re-ordered into MFMA fragment order by the pack calls (one launch each):
+ *   pack_forward : Pz, Pr, Pn          [G, dpk_gru_pack_floats(H, 2H)]
+ *   pack_backward: Pnx, Pnh            [G, dpk_gru_pack_floats(H, H)]     W_new^T, input / hidden half
+ *                  Pzrx, Pzrh          [G, dpk_gru_pack_floats(H, 2H)]    [W_update; W_reset]^T, input / hidden half
+ *
+ * forward:  xp[g] [B,T,H]; h0 NULL or h0[g] [B,H] (NULL entry = zeros); bias[3g+0..2] = {update, reset, new} biases.
+ *   writes out = h_t, the gate activations Z, R, N ([G,B,T,H]) and the gates' stacked input activations
+ *   Azr = [xp_t | h_{t-1}] (update, reset) and An = [xp_t | r_t*h_{t-1}] (new), both [G,B,T,2H] — exactly the `A`
+ *   operand dpk_linear_grad_sample contracts with K = T.
+ * backward: dout[g] [B,T,H] = dL/dout (NULL entry = zeros); dhT NULL or dhT[g] [B,H] added at t = T-1.
+ *   writes dxp [G,B,T,H], the gates' pre-activation gradients Gz, Gr, Gn [G,B,T,H] (the `G` operands of
+ *   dpk_linear_grad_sample) and, if non-NULL, dh0 [G,B,H].
  */
+#define DPK_GRU_MAX_G 8
 int64_t dpk_gru_pack_floats(int O, int K);
-int dpk_gru_pack(const float* src, int ld, int coff, int O, int K, int transposed, float* dst, void* stream);
-int dpk_gru_forward(const float* xp, const float* h0, const float* Pz, const float* Pr, const float* Pn,
-                    const float* bz, const float* br, const float* bn, float* out, float* Z, float* R,
-                    float* N, float* RH, int B, int T, int H, int G, void* stream);
-int dpk_gru_backward(const float* dout, const float* dhT, const float* Z, const float* R, const float* N,
-                     const float* hall, const float* h0, const float* Pnx, const float* Pnh,
+int dpk_gru_pack_forward(const float* const* W, int ld, float* Pz, float* Pr, float* Pn, int H, int G, void* stream);
+int dpk_gru_pack_backward(const float* const* W, int ld, float* Pnx, float* Pnh, float* Pzrx, float* Pzrh,
+                          int H, int G, void* stream);
+int dpk_gru_forward(const float* const* xp, const float* const* h0, const float* Pz, const float* Pr,
+                    const float* Pn, const float* const* bias, float* out, float* Z, float* R, float* N,
+                    float* Azr, float* An, int B, int T, int H, int G, void* stream);
+int dpk_gru_backward(const float* const* dout, const float* const* dhT, const float* Z, const float* R,
+                     const float* N, const float* Azr, const float* Pnx, const float* Pnh,
                      const float* Pzrx, const float* Pzrh, float* dxp, float* Gz, float* Gr, float* Gn,
                      float* dh0, int B, int T, int H, int G, void* stream);
 

@@ -36,21 +36,19 @@ def bench_reduce(B, P):
     print(f"K7 B={B} P={P}: {ms*1e3:8.1f} us  read {B*P*4/ms/1e6:7.1f} GB/s (ws {ws_b>>20} MiB)")
 
 def bench_gru(B, T, H, G=1):
-    xp = torch.randn(G, B, T, H, device="cuda")
-    W = [torch.randn(H, 2 * H, device="cuda") / (2 * H) ** 0.5 for _ in range(3)]
-    b = [torch.zeros(G, H, device="cuda") for _ in range(3)]
-    P = [nat.gru_pack(w, H, 2 * H, False).repeat(G, 1) for w in W]
-    out, Z, R, N, RH = nat.gru_forward(xp, None, *P, *b)
-    ms_f = timeit(lambda: nat.gru_forward(xp, None, *P, *b))
-    wzr = torch.cat(W[:2], 0)
-    pb = [nat.gru_pack(W[2], H, H, True, 0), nat.gru_pack(W[2], H, H, True, H),
-          nat.gru_pack(wzr, H, 2 * H, True, 0), nat.gru_pack(wzr, H, 2 * H, True, H)]
-    pb = [p.repeat(G, 1) for p in pb]
-    dout = torch.randn(G, B, T, H, device="cuda")
-    ms_b = timeit(lambda: nat.gru_backward(dout, None, Z, R, N, out, None, *pb, False))
+    xps = [torch.randn(B, T, H, device="cuda") for _ in range(G)]
+    W = [torch.randn(H, 2 * H, device="cuda") / (2 * H) ** 0.5 for _ in range(3 * G)]
+    b = [torch.zeros(H, device="cuda") for _ in range(3 * G)]
+    P = nat.gru_pack_forward(W, H)
+    out, Z, R, N, Azr, An = nat.gru_forward(xps, None, *P, b)
+    ms_f = timeit(lambda: nat.gru_forward(xps, None, *P, b))
+    pb = nat.gru_pack_backward(W, H)
+    douts = [torch.randn(B, T, H, device="cuda") for _ in range(G)]
+    ms_b = timeit(lambda: nat.gru_backward(douts, None, Z, R, N, Azr, *pb, False))
+    ms_p = timeit(lambda: (nat.gru_pack_forward(W, H), nat.gru_pack_backward(W, H)))
     flops = 2.0 * G * B * T * 6 * H * H
     print(f"K8 G={G} B={B} T={T} H={H}: fwd {ms_f*1e3:8.1f} us ({flops/ms_f/1e9:5.1f} TFLOP/s)  bwd {ms_b*1e3:8.1f} us "
-          f"({flops/ms_b/1e9:5.1f} TFLOP/s)  per step fwd {ms_f*1e3/T:6.2f} us bwd {ms_b*1e3/T:6.2f} us")
+          f"({flops/ms_b/1e9:5.1f} TFLOP/s)  per step fwd {ms_f*1e3/T:6.2f} us bwd {ms_b*1e3/T:6.2f} us  packs {ms_p*1e3:5.1f} us")
 
 
 if __name__ == "__main__":

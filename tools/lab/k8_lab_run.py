@@ -8,12 +8,12 @@ nat.LIB_PATH = os.path.join(here, "libdpk_lab.so")
 lib = nat.load()
 names = ["x->LDS", "barrier0", "phase1 mfma", "phase1 epilogue", "barrier1", "phase2 mfma", "phase2 epilogue", "barrier2"]
 for (B, T, H) in ((1024, 24, 128), (1024, 24, 200)):
-    xp = torch.randn(1, B, T, H, device="cuda")
+    xp = [torch.randn(B, T, H, device="cuda")]
     W = [torch.randn(H, 2 * H, device="cuda") / (2 * H) ** 0.5 for _ in range(3)]
-    b = [torch.zeros(1, H, device="cuda") for _ in range(3)]
-    P = [nat.gru_pack(w, H, 2 * H, False).unsqueeze(0) for w in W]
+    b = [torch.zeros(H, device="cuda") for _ in range(3)]
+    P = nat.gru_pack_forward(W, H)
     for _ in range(3):
-        nat.gru_forward(xp, None, *P, *b)
+        nat.gru_forward(xp, None, *P, b)
     torch.cuda.synchronize()
     buf = (ctypes.c_longlong * 128)()
     lib.k8_dbg_read(buf)
