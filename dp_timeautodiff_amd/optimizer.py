@@ -279,7 +279,14 @@ class DPOptimizer(Optimizer):
         if self._gsm is not None:
             for layer in self._gsm._layers:
                 layer.passes_written = 0
-        self.original_optimizer.zero_grad(set_to_none)
+        if not set_to_none and arena is not None and arena.grad is not None and self._grads_live_in(arena):
+            arena.grad.zero_()  # every p.grad is a view of this one vector: one fill instead of one per parameter
+        else:
+            self.original_optimizer.zero_grad(set_to_none)
+
+    def _grads_live_in(self, arena) -> bool:
+        base = arena.grad.untyped_storage().data_ptr()
+        return all(p.grad is not None and p.grad.untyped_storage().data_ptr() == base for p in self.params)
 
     # ---- last-step diagnostics (device tensors, valid after step()) ------------------------------------
     @property
