@@ -43,6 +43,10 @@ EXPORTS = {
                                       c_void_p]),
     "dpk_philox_normal": (c_int, [c_void_p, c_int64, c_uint64, c_uint64, c_float, c_void_p]),
     "dpk_adam_step": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_int64, c_void_p]),
+    "dpk_lstm_pack_forward": (c_int, [c_void_p, c_void_p, c_int, c_int, c_void_p]),
+    "dpk_lstm_pack_backward": (c_int, [c_void_p, c_void_p, c_int, c_int, c_void_p]),
+    "dpk_lstm_forward": (c_int, [c_void_p] * 9 + [c_int] * 5 + [c_void_p]),
+    "dpk_lstm_backward": (c_int, [c_void_p] * 8 + [c_int] * 5 + [c_void_p]),
     "dpk_gru_pack_floats": (c_int64, [c_int, c_int]),
     "dpk_gru_pack_forward": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p]),
     "dpk_gru_pack_backward": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int,
@@ -368,6 +372,77 @@ def gru_backward(douts, dhTs, Z, R, N, Azr, Pnx, Pnh, Pzrx, Pzrh, want_dh0: bool
                                  _stream())
     _check(rc, "dpk_gru_backward")
     return dxp, Gz, Gr, Gn, dh0
+
+
+# ---- K10: fused DPLSTM recurrence -----------------------------------------------------------------------------------
+
+LSTM_MAX_HIDDEN = 256
+
+
+def lstm_pack_forward(whh, H: int):
+    G = len(whh)
+    arr = _ptr_array(whh, "Whh", (4 * H, H))
+    P = torch.empty(G, 4, gru_pack_floats(H, H), device=whh[0].device, dtype=torch.float32)
+    _check(load().dpk_lstm_pack_forward(arr, _ptr(P), H, G, _stream()), "dpk_lstm_pack_forward")
+    return P
+
+
+def lstm_pack_backward(whh, H: int):
+    G = len(whh)
+    arr = _ptr_array(whh, "Whh", (4 * H, H))
+    Pt = torch.empty(G, gru_pack_floats(H, 4 * H), device=whh[0].device, dtype=torch.float32)
+    _check(load().dpk_lstm_pack_backward(arr, _ptr(Pt), H, G, _stream()), "dpk_lstm_pack_backward")
+    return Pt
+
+
+def lstm_forward(xgs, h0s, c0s, bhhs, P, reverse_mask: int):
+    """xgs: G tensors [B,T,4H]; h0s/c0s: None or G tensors [B,H]; bhhs: None or G tensors [4H].
+    Returns out, gates [G,B,T,4H], C, Hprev ([G,B,T,H] unless noted)."""
+    G = len(xgs)
+    _req(xgs[0], "xg[0]")
+    if G == 0 or G > GRU_MAX_G or xgs[0].dim() != 3 or xgs[0].shape[2] % 4:
+        raise DpkError("lstm_forward: xg must be G <= 8 tensors [B,T,4H]")
+    B, T, H4 = xgs[0].shape
+    H = H4 // 4
+    if B == 0 or T == 0:
+        raise DpkError("lstm_forward: empty batch / sequence")
+    xa = _ptr_array(xgs, "xg", (B, T, 4 * H))
+    ha = None if h0s is None else _ptr_array(h0s, "h0", (B, H))
+    ca = None if c0s is None else _ptr_array(c0s, "c0", (B, H))
+    ba = None if bhhs is None else _ptr_array(bhhs, "bhh", (4 * H,))
+    _req(P, "P")
+    if tuple(P.shape) != (G, 4, gru_pack_floats(H, H)) or not P.is_contiguous():
+        raise DpkError("lstm_forward: P is not [G, 4, packed(H,H)]")
+    dev = xgs[0].device
+    out, C, Hprev = (torch.empty(G, B, T, H, device=dev, dtype=torch.float32) for _ in range(3))
+    gates = torch.empty(G, B, T, 4 * H, device=dev, dtype=torch.float32)
+    rc = load().dpk_lstm_forward(xa, ha, ca, ba, _ptr(P), _ptr(out), _ptr(gates), _ptr(C), _ptr(Hprev),
+                                 int(reverse_mask), B, T, H, G, _stream())
+    _check(rc, "dpk_lstm_forward")
+    return out, gates, C, Hprev
+
+
+def lstm_backward(douts, c0s, gates, C, Pt, reverse_mask: int, want_d0: bool):
+    """Returns dpre [G,B,T,4H] and (dh0, dc0) [G,B,H] or (None, None)."""
+    _req(C, "C"); _req(gates, "gates"); _req(Pt, "Pt")
+    if C.dim() != 4 or not C.is_contiguous():
+        raise DpkError("lstm_backward: C must be contiguous [G,B,T,H]")
+    G, B, T, H = C.shape
+    if tuple(gates.shape) != (G, B, T, 4 * H) or not gates.is_contiguous():
+        raise DpkError("lstm_backward: gates must be contiguous [G,B,T,4H]")
+    if tuple(Pt.shape) != (G, gru_pack_floats(H, 4 * H)) or not Pt.is_contiguous():
+        raise DpkError("lstm_backward: Pt has the wrong packed size")
+    if len(douts) != G or (c0s is not None and len(c0s) != G):
+        raise DpkError("lstm_backward: inconsistent number of recurrences")
+    da = _ptr_array(douts, "dout", (B, T, H), allow_none=True)
+    ca = None if c0s is None else _ptr_array(c0s, "c0", (B, H))
+    dpre = torch.empty_like(gates)
+    dh0 = torch.empty(G, B, H, device=C.device, dtype=torch.float32) if want_d0 else None
+    dc0 = torch.empty(G, B, H, device=C.device, dtype=torch.float32) if want_d0 else None
+    rc = load().dpk_lstm_backward(da, ca, _ptr(gates), _ptr(C), _ptr(Pt), _ptr(dpre), _ptr(dh0), _ptr(dc0),
+                                  int(reverse_mask), B, T, H, G, _stream())
+    _check(rc, "dpk_lstm_backward")
+    return dpre, dh0, dc0
 
 
 # ---- K9: Adam on the arena-layout gradient ------------------------------------------------------------------------

@@ -1,0 +1,442 @@
+// K10 — fused DPLSTM recurrence (forward and backward): SURVEY.md §8f-1 for the denoiser (cfg3).
+// Opacus' DPLSTM (what ModuleValidator.fix makes of the nn.LSTM at Model_Code/timediffusion.py:106) runs, per layer
+// and direction, a T-step Python loop of two RNNLinear cells (ih: in->4H, hh: H->4H) plus elementwise gate math.
+// Here the input projection of ALL time steps is one ordinary Linear call outside (xg = ih(x), [B,T,4H]) and ONE launch
+// runs the whole recurrence for G independent (layer-mate) directions:
+//
+//   g_t = xg_t + Whh h_{t-1} + bhh      i,f,o = sigmoid, g = tanh      c_t = f c_{t-1} + i g      h_t = o tanh(c_t)
+//
+// Same tile scheme as K8 (rnn_tile.h): a workgroup owns 16 batch rows for all T steps; D[out][batch] accumulators put
+// the four gates, c and h of one (feature, row) element in the same lane in every step, so the cell state and the
+// carried dh / dc never leave registers.  The backward kernel writes the pre-activation gradient dpre [B,T,4H]: it is
+// at once dL/dxg (autograd continues into ih, whose hook hands (x, dpre) to K1) and the `G` operand of hh's
+// per-sample-gradient contraction with A = h_{t-1} [B,T,H], which the forward kernel stored.
+// H need not be a multiple of 4 (the reference uses H = 250): row accesses fall back to 8-byte / scalar pieces.
+#include "rnn_tile.h"
+
+namespace {
+
+__device__ __forceinline__ f32x4 ldv(const float* p, int nv) {
+    f32x4 v = {0.f, 0.f, 0.f, 0.f};
+    if (nv >= 4 && ((uintptr_t)p & 15) == 0) return ld4(p);
+#pragma unroll
+    for (int e = 0; e < 4; ++e)
+        if (e < nv) v[e] = p[e];
+    return v;
+}
+__device__ __forceinline__ void stv(float* p, f32x4 v, int nv) {
+    if (nv >= 4 && ((uintptr_t)p & 15) == 0) { st4(p, v); return; }
+#pragma unroll
+    for (int e = 0; e < 4; ++e)
+        if (e < nv) p[e] = v[e];
+}
+__device__ __forceinline__ void lds_colv(float* s, int o, int j, f32x4 v, int nv) {
+#pragma unroll
+    for (int e = 0; e < 4; ++e)
+        if (e < nv) s[(o + e) * GBT + j] = v[e];
+}
+
+// four gates sharing the B operand: four independent accumulator chains, two K groups of weights in flight per gate
+__device__ __forceinline__ void mfma_tile4(f32x4 (&a)[4], const f32x4* __restrict__ wp, int64_t gate_stride,
+                                           const float* __restrict__ sB, int KG, int lane) {
+    constexpr int GPF = 2;
+    const int q = lane >> 4, j = lane & 15;
+    const float* p = sB + q * GBT + j;
+    const f32x4* pw[4];
+    f32x4 w[4][GPF];
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+        pw[g] = wp + g * gate_stride + lane;
+#pragma unroll
+        for (int s = 0; s < GPF; ++s) w[g][s] = pw[g][(s < KG ? s : KG - 1) * 64];
+    }
+    BFrag bc = ld_bfrag(p);
+    int kg = 0;
+    for (; kg + 2 * GPF <= KG; kg += GPF) {
+#pragma unroll
+        for (int s = 0; s < GPF; ++s) {
+            p += 16 * GBT;
+            const BFrag bn = ld_bfrag(p);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                DPK_MFMA4(a[g], w[g][s], bc.b0, bc.b1, bc.b2, bc.b3);
+                w[g][s] = pw[g][(kg + s + GPF) * 64];
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            bc = bn;
+        }
+    }
+    const int rem = KG - kg;
+#pragma unroll
+    for (int s = 0; s < GPF; ++s) {
+        if (s < rem) {
+            const float* pn = p + (s + 1 < rem ? 16 * GBT : 0);
+            const BFrag bn = ld_bfrag(pn);
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                DPK_MFMA4(a[g], w[g][s], bc.b0, bc.b1, bc.b2, bc.b3);
+                if (s + GPF < rem) w[g][s] = pw[g][(kg + s + GPF) * 64];
+            }
+            p = pn;
+            bc = bn;
+        }
+    }
+#pragma unroll
+    for (int s = 0; s < GPF; ++s) {
+        if (s + GPF < rem) {
+            const float* pn = p + (s + GPF + 1 < rem ? 16 * GBT : 0);
+            const BFrag bn = ld_bfrag(pn);
+#pragma unroll
+            for (int g = 0; g < 4; ++g) { DPK_MFMA4(a[g], w[g][s], bc.b0, bc.b1, bc.b2, bc.b3); }
+            p = pn;
+            bc = bn;
+        }
+    }
+}
+
+template <int TPW>
+__global__ void __launch_bounds__(GNW * 64) lstm_fwd_kernel(GPtrs xgs, GPtrs h0s, GPtrs c0s, GPtrs bhhs,
+                                                            const f32x4* __restrict__ P, float* __restrict__ out,
+                                                            float* __restrict__ gates, float* __restrict__ C,
+                                                            float* __restrict__ Hprev, int reverse_mask, int B, int T,
+                                                            int H) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    constexpr int NTH = GNW * 64;
+    const int KG = (H + 15) / 16, NT = KG;
+    float* hT = smem;  // [KG*16][16]  h_{t-1}, k-major, zero padded
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int j = lane & 15, q = lane >> 4;
+    const int b = blockIdx.x * GBT + j;
+    const bool bvalid = b < B;
+    const int gi = blockIdx.y;
+    const bool rev = (reverse_mask >> gi) & 1;
+    const float* __restrict__ xg = xgs.p[gi];
+    const float* __restrict__ h0 = h0s.p[gi];
+    const float* __restrict__ c0 = c0s.p[gi];
+    const float* __restrict__ bhh = bhhs.p[gi];
+    const int64_t gate_stride = (int64_t)NT * KG * 64;
+    {
+        const int64_t g = gi, gx = g * B * T * H;
+        out += gx; C += gx; Hprev += gx; gates += 4 * gx;
+        P += g * 4 * gate_stride;
+    }
+    for (int i = threadIdx.x; i < KG * 16 * GBT; i += NTH) smem[i] = 0.f;
+    __syncthreads();
+
+    f32x4 hreg[TPW], creg[TPW], bias[TPW][4], xpre[TPW][4];
+    const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int i = 0; i < TPW; ++i) {
+        const int o = (wave + GNW * i) * 16 + q * 4;
+        const int nv = min(4, H - o);
+        hreg[i] = creg[i] = zero4;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) bias[i][g] = (nv > 0 && bhh) ? ldv(bhh + g * H + o, nv) : zero4;
+        if (nv > 0 && bvalid) {
+            if (h0) hreg[i] = ldv(h0 + (int64_t)b * H + o, nv);
+            if (c0) creg[i] = ldv(c0 + (int64_t)b * H + o, nv);
+        }
+        if (nv > 0) lds_colv(hT, o, j, hreg[i], nv);
+    }
+    auto load_x = [&](int t) {
+#pragma unroll
+        for (int i = 0; i < TPW; ++i) {
+            const int o = (wave + GNW * i) * 16 + q * 4;
+            const int nv = min(4, H - o);
+#pragma unroll
+            for (int g = 0; g < 4; ++g)
+                xpre[i][g] = (nv > 0 && bvalid) ? ldv(xg + ((int64_t)b * T + t) * 4 * H + g * H + o, nv) : zero4;
+        }
+    };
+    load_x(rev ? T - 1 : 0);
+    lds_barrier();
+
+    for (int s = 0; s < T; ++s) {
+        const int t = rev ? T - 1 - s : s;
+        f32x4 hnew[TPW];
+#pragma unroll
+        for (int i = 0; i < TPW; ++i) {
+            const int ot = wave + GNW * i;
+            const int o = ot * 16 + q * 4;
+            const int nv = min(4, H - o);
+            hnew[i] = zero4;
+            f32x4 a[4];
+#pragma unroll
+            for (int g = 0; g < 4; ++g) a[g] = xpre[i][g] + bias[i][g];
+            if (i == TPW - 1 && s + 1 < T) load_x(rev ? t - 1 : t + 1);  // operands of the next step, in flight
+            if (ot < NT) {
+                mfma_tile4(a, P + (int64_t)ot * KG * 64, gate_stride, hT, KG, lane);
+                if (nv > 0) {
+                    f32x4 ig, fg, gg, og, tc;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        ig[e] = sigmoidf_(a[0][e]);
+                        fg[e] = sigmoidf_(a[1][e]);
+                        gg[e] = tanhf_(a[2][e]);
+                        og[e] = sigmoidf_(a[3][e]);
+                    }
+                    const f32x4 c = fg * creg[i] + ig * gg;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) tc[e] = tanhf_(c[e]);
+                    hnew[i] = og * tc;
+                    creg[i] = c;
+                    if (bvalid) {
+                        const int64_t r = (int64_t)b * T + t;
+                        stv(gates + r * 4 * H + 0 * H + o, ig, nv);
+                        stv(gates + r * 4 * H + 1 * H + o, fg, nv);
+                        stv(gates + r * 4 * H + 2 * H + o, gg, nv);
+                        stv(gates + r * 4 * H + 3 * H + o, og, nv);
+                        stv(C + r * H + o, c, nv);
+                        stv(Hprev + r * H + o, hreg[i], nv);
+                        stv(out + r * H + o, hnew[i], nv);
+                    }
+                }
+            }
+        }
+        lds_barrier();  // every wave has finished reading h_{t-1}
+#pragma unroll
+        for (int i = 0; i < TPW; ++i) {
+            const int o = (wave + GNW * i) * 16 + q * 4;
+            const int nv = min(4, H - o);
+            hreg[i] = hnew[i];
+            if (wave + GNW * i < NT && nv > 0) lds_colv(hT, o, j, hnew[i], nv);
+        }
+        lds_barrier();
+    }
+}
+
+template <int TPW>
+__global__ void __launch_bounds__(GNW * 64) lstm_bwd_kernel(GPtrs douts, GPtrs c0s, const float* __restrict__ gates,
+                                                            const float* __restrict__ C,
+                                                            const f32x4* __restrict__ Pt, float* __restrict__ dpre,
+                                                            float* __restrict__ dh0, float* __restrict__ dc0,
+                                                            int reverse_mask, int B, int T, int H) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    constexpr int NTH = GNW * 64;
+    const int NT = (H + 15) / 16;
+    const int KG4 = (4 * H + 15) / 16;
+    float* sD = smem;  // [KG4*16][16]  dpre_t, rows g*H + o, k-major, zero padded
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int j = lane & 15, q = lane >> 4;
+    const int b = blockIdx.x * GBT + j;
+    const bool bvalid = b < B;
+    const int gi = blockIdx.y;
+    const bool rev = (reverse_mask >> gi) & 1;
+    const float* __restrict__ dout = douts.p[gi];
+    const float* __restrict__ c0 = c0s.p[gi];
+    {
+        const int64_t g = gi, gx = g * B * T * H;
+        gates += 4 * gx; C += gx; dpre += 4 * gx;
+        if (dh0) dh0 += g * B * H;
+        if (dc0) dc0 += g * B * H;
+        Pt += g * NT * KG4 * 64;
+    }
+    for (int i = threadIdx.x; i < KG4 * 16 * GBT; i += NTH) smem[i] = 0.f;
+    __syncthreads();
+
+    const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
+    f32x4 dhc[TPW], dcc[TPW];
+    f32x4 p_do[TPW], p_g[TPW][4], p_c[TPW], p_cp[TPW];
+#pragma unroll
+    for (int i = 0; i < TPW; ++i) dhc[i] = dcc[i] = zero4;
+    // processing order of the forward pass was s = 0..T-1 (t = s, or T-1-s when reversed); walk it backwards
+    auto load_step = [&](int s) {
+        const int t = rev ? T - 1 - s : s;
+        const int tp = rev ? t + 1 : t - 1;  // time index of the step processed before it
+#pragma unroll
+        for (int i = 0; i < TPW; ++i) {
+            const int o = (wave + GNW * i) * 16 + q * 4;
+            const int nv = min(4, H - o);
+            p_do[i] = p_c[i] = p_cp[i] = zero4;
+#pragma unroll
+            for (int g = 0; g < 4; ++g) p_g[i][g] = zero4;
+            if (nv > 0 && bvalid) {
+                const int64_t r = (int64_t)b * T + t;
+                if (dout) p_do[i] = ldv(dout + r * H + o, nv);
+#pragma unroll
+                for (int g = 0; g < 4; ++g) p_g[i][g] = ldv(gates + r * 4 * H + g * H + o, nv);
+                p_c[i] = ldv(C + r * H + o, nv);
+                if (s > 0) p_cp[i] = ldv(C + ((int64_t)b * T + tp) * H + o, nv);
+                else if (c0) p_cp[i] = ldv(c0 + (int64_t)b * H + o, nv);
+            }
+        }
+    };
+    load_step(T - 1);
+
+    for (int s = T - 1; s >= 0; --s) {
+        const int t = rev ? T - 1 - s : s;
+#pragma unroll
+        for (int i = 0; i < TPW; ++i) {
+            const int ot = wave + GNW * i;
+            const int o = ot * 16 + q * 4;
+            const int nv = min(4, H - o);
+            if (ot < NT && nv > 0) {
+                const f32x4 ig = p_g[i][0], fg = p_g[i][1], gg = p_g[i][2], og = p_g[i][3];
+                f32x4 tc;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) tc[e] = tanhf_(p_c[i][e]);
+                const f32x4 dh = p_do[i] + dhc[i];
+                const f32x4 dc = dcc[i] + dh * og * (1.0f - tc * tc);
+                const f32x4 di = dc * gg * ig * (1.0f - ig);
+                const f32x4 df = dc * p_cp[i] * fg * (1.0f - fg);
+                const f32x4 dg = dc * ig * (1.0f - gg * gg);
+                const f32x4 dO = dh * tc * og * (1.0f - og);
+                dcc[i] = dc * fg;
+                if (bvalid) {
+                    const int64_t r = ((int64_t)b * T + t) * 4 * H + o;
+                    stv(dpre + r + 0 * H, di, nv);
+                    stv(dpre + r + 1 * H, df, nv);
+                    stv(dpre + r + 2 * H, dg, nv);
+                    stv(dpre + r + 3 * H, dO, nv);
+                }
+                lds_colv(sD, 0 * H + o, j, di, nv);  // batch columns beyond B carry zeros (their operands were zero)
+                lds_colv(sD, 1 * H + o, j, df, nv);
+                lds_colv(sD, 2 * H + o, j, dg, nv);
+                lds_colv(sD, 3 * H + o, j, dO, nv);
+            }
+        }
+        lds_barrier();
+        if (s > 0) load_step(s - 1);
+        // dh_{t-1} = Whh^T dpre_t
+        if (TPW == 1) {
+            dhc[0] = zero4;
+            if (wave < NT) mfma_tile<4>(dhc[0], Pt + (int64_t)wave * KG4 * 64, sD, KG4, lane);
+        } else {
+#pragma unroll
+            for (int i = 0; i < TPW; i += 2) {
+                const int ot0 = wave + GNW * i, ot1 = wave + GNW * (i + 1);
+                dhc[i] = dhc[i + 1] = zero4;
+                if (ot1 < NT)
+                    mfma_tile2<4>(dhc[i], dhc[i + 1], Pt + (int64_t)ot0 * KG4 * 64, Pt + (int64_t)ot1 * KG4 * 64, sD, KG4,
+                                  lane);
+                else if (ot0 < NT)
+                    mfma_tile<4>(dhc[i], Pt + (int64_t)ot0 * KG4 * 64, sD, KG4, lane);
+            }
+        }
+        lds_barrier();  // sD is rewritten by the next (earlier) step
+    }
+#pragma unroll
+    for (int i = 0; i < TPW; ++i) {
+        const int o = (wave + GNW * i) * 16 + q * 4;
+        const int nv = min(4, H - o);
+        if (wave + GNW * i < NT && nv > 0 && bvalid) {
+            if (dh0) stv(dh0 + (int64_t)b * H + o, dhc[i], nv);
+            if (dc0) stv(dc0 + (int64_t)b * H + o, dcc[i], nv);
+        }
+    }
+}
+
+inline int lstm_tpw(int H) {
+    const int per = ((H + 15) / 16 + GNW - 1) / GNW;
+    return per <= 1 ? 1 : per <= 2 ? 2 : 0;
+}
+
+int lstm_check(int B, int T, int H, int G) {
+    if (B <= 0 || T <= 0 || H <= 0 || G <= 0) return DPK_EINVAL;
+    if (G > GMAX || !lstm_tpw(H)) return DPK_ERANGE;
+    return DPK_OK;
+}
+
+}  // namespace
+
+extern "C" int dpk_lstm_pack_forward(const float* const* Whh, float* P, int H, int G, void* stream) {
+    if (!Whh || !P || H <= 0 || G <= 0) return DPK_EINVAL;
+    if (G > GMAX) return DPK_ERANGE;
+    if (!dpk_aligned16(P)) return DPK_EALIGN;
+    const int64_t n = dpk_gru_pack_floats(H, H);
+    PackJobs jobs{};
+    for (int g = 0; g < G; ++g) {
+        if (!Whh[g]) return DPK_EINVAL;
+        for (int k = 0; k < 4; ++k) {  // gate k: rows [kH, (k+1)H) of Whh [4H, H]
+            const int y = g * 4 + k;
+            jobs.src[y] = jobs.src2[y] = Whh[g] + (int64_t)k * H * H;
+            jobs.dst[y] = P + (g * 4 + k) * n;
+            jobs.coff[y] = 0;
+            jobs.K[y] = H;
+            jobs.transposed[y] = 0;
+        }
+    }
+    return rnn_launch_pack(jobs, 4 * G, H, H, H, (hipStream_t)stream);
+}
+
+extern "C" int dpk_lstm_pack_backward(const float* const* Whh, float* Pt, int H, int G, void* stream) {
+    if (!Whh || !Pt || H <= 0 || G <= 0) return DPK_EINVAL;
+    if (G > GMAX) return DPK_ERANGE;
+    if (!dpk_aligned16(Pt)) return DPK_EALIGN;
+    const int64_t n = dpk_gru_pack_floats(H, 4 * H);
+    PackJobs jobs{};
+    for (int g = 0; g < G; ++g) {
+        if (!Whh[g]) return DPK_EINVAL;
+        jobs.src[g] = Whh[g];                       // W(out=o, k) = Whh[k][o], k over all 4H rows
+        jobs.src2[g] = Whh[g] + (int64_t)H * H;     // rows >= H continue in the same matrix
+        jobs.dst[g] = Pt + g * n;
+        jobs.coff[g] = 0;
+        jobs.K[g] = 4 * H;
+        jobs.transposed[g] = 1;
+    }
+    return rnn_launch_pack(jobs, G, H, H, 4 * H, (hipStream_t)stream);
+}
+
+extern "C" int dpk_lstm_forward(const float* const* xg, const float* const* h0, const float* const* c0,
+                                const float* const* bhh, const float* P, float* out, float* gates, float* C,
+                                float* Hprev, int reverse_mask, int B, int T, int H, int G, void* stream) {
+    if (!xg || !P || !out || !gates || !C || !Hprev) return DPK_EINVAL;
+    if (int rc = lstm_check(B, T, H, G)) return rc;
+    if (!dpk_aligned16(P) || !dpk_aligned16(out) || !dpk_aligned16(gates) || !dpk_aligned16(C) ||
+        !dpk_aligned16(Hprev))
+        return DPK_EALIGN;
+    GPtrs xs{}, hs{}, cs{}, bs{};
+    for (int g = 0; g < G; ++g) {
+        if (!xg[g]) return DPK_EINVAL;
+        xs.p[g] = xg[g];
+        hs.p[g] = h0 ? h0[g] : nullptr;
+        cs.p[g] = c0 ? c0[g] : nullptr;
+        bs.p[g] = bhh ? bhh[g] : nullptr;
+        // per-recurrence inputs may be arbitrary fp32 views (e.g. rows of a [L*D,B,H] state): the kernel checks each
+        // row access and falls back to scalar pieces where it is not 16-byte aligned
+    }
+    const size_t lds = (size_t)((H + 15) / 16) * 16 * GBT * sizeof(float);
+    dim3 grid((unsigned)((B + GBT - 1) / GBT), (unsigned)G);
+    hipStream_t s = (hipStream_t)stream;
+    if (lstm_tpw(H) == 1)
+        hipLaunchKernelGGL((lstm_fwd_kernel<1>), grid, dim3(GNW * 64), lds, s, xs, hs, cs, bs, (const f32x4*)P, out,
+                           gates, C, Hprev, reverse_mask, B, T, H);
+    else
+        hipLaunchKernelGGL((lstm_fwd_kernel<2>), grid, dim3(GNW * 64), lds, s, xs, hs, cs, bs, (const f32x4*)P, out,
+                           gates, C, Hprev, reverse_mask, B, T, H);
+    return dpk_launch_status();
+}
+
+extern "C" int dpk_lstm_backward(const float* const* dout, const float* const* c0, const float* gates,
+                                 const float* C, const float* Pt, float* dpre, float* dh0, float* dc0,
+                                 int reverse_mask, int B, int T, int H, int G, void* stream) {
+    if (!dout || !gates || !C || !Pt || !dpre) return DPK_EINVAL;
+    if (int rc = lstm_check(B, T, H, G)) return rc;
+    const void* ptrs[] = {gates, C, Pt, dpre, dh0, dc0};
+    for (const void* p : ptrs)
+        if (p && !dpk_aligned16(p)) return DPK_EALIGN;
+    GPtrs ds{}, cs{};
+    for (int g = 0; g < G; ++g) {
+        ds.p[g] = dout[g];
+        cs.p[g] = c0 ? c0[g] : nullptr;
+    }
+    const size_t lds = (size_t)((4 * H + 15) / 16) * 16 * GBT * sizeof(float);
+    if (lds > 150 * 1024) return DPK_ERANGE;
+    dim3 grid((unsigned)((B + GBT - 1) / GBT), (unsigned)G);
+    hipStream_t s = (hipStream_t)stream;
+#define DPK_LSTM_B(TPW)                                                                                             \
+    do {                                                                                                            \
+        if (lds > 64 * 1024) {                                                                                      \
+            hipError_t e_ = hipFuncSetAttribute((const void*)lstm_bwd_kernel<TPW>,                                  \
+                                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);              \
+            if (e_ != hipSuccess) return (int)e_;                                                                   \
+        }                                                                                                           \
+        hipLaunchKernelGGL((lstm_bwd_kernel<TPW>), grid, dim3(GNW * 64), lds, s, ds, cs, gates, C,                  \
+                           (const f32x4*)Pt, dpre, dh0, dc0, reverse_mask, B, T, H);                                \
+    } while (0)
+    if (lstm_tpw(H) == 1) DPK_LSTM_B(1);
+    else DPK_LSTM_B(2);
+#undef DPK_LSTM_B
+    return dpk_launch_status();
+}

@@ -266,7 +266,7 @@ class GradSampleModule(nn.Module):
         # fused recurrences hand their gates' stacked (activations, backprops) over directly (no per-call hooks)
         self._by_module = {id(l.module): l for l in self._layers}
         for sub in m.modules():
-            if isinstance(sub, FusedLinearCellGRU):
+            if isinstance(sub, FusedLinearCellGRU) or "_dpk_sink" in sub.__dict__:  # fused GRU modules, DPLSTM cells
                 object.__setattr__(sub, "_dpk_sink", self._fused_sink)
                 object.__setattr__(sub, "_dpk_sink_active", lambda: self.hooks_enabled)
         for n_, p in params:
@@ -333,8 +333,9 @@ class GradSampleModule(nn.Module):
     def _close(self):
         self.remove_hooks()
         for sub in self._module.modules():
-            if isinstance(sub, FusedLinearCellGRU):
-                sub._init_runtime()
+            if "_dpk_sink" in sub.__dict__:
+                object.__setattr__(sub, "_dpk_sink", None)
+                object.__setattr__(sub, "_dpk_sink_active", None)
         for p in self._module.parameters():
             for attr in ("grad_sample", "_forward_counter", "_dpk_arena", "summed_grad"):
                 if hasattr(p, attr):
@@ -408,11 +409,12 @@ class GradSampleModule(nn.Module):
         return hook
 
     # ---- the deferred contraction ---------------------------------------------------------------------
-    def _stack(self, tensors: List[torch.Tensor], feat_dims: int) -> torch.Tensor:
+    def _stack(self, tensors: List[torch.Tensor], feat_dims: int, batch_first: Optional[bool] = None) -> torch.Tensor:
         """calls x [B, *, F]  ->  contiguous [B, T_total, F] (feat_dims=1) or [B, T_total] (indices)."""
+        batch_first = self.batch_first if batch_first is None else batch_first
         flat = []
         for t in tensors:
-            if not self.batch_first and t.dim() >= 2 + feat_dims:
+            if not batch_first and t.dim() >= 2 + feat_dims:
                 t = t.transpose(0, 1)
             if feat_dims == 0:
                 flat.append(t.reshape(t.shape[0], -1))
@@ -432,11 +434,12 @@ class GradSampleModule(nn.Module):
         pairs = layer.pairs[::-1]  # back to forward order (t ascending)
         layer.pairs = []
         m = layer.module
+        bf = True if isinstance(m, RNNLinear) else None  # DP RNN cells are always called batch-major
         if layer.kind == "embedding":
             A = self._stack([p[0] for p in pairs], 0).to(torch.int64)
         else:
-            A = self._stack([p[0] for p in pairs], 1)
-        G = self._stack([p[1] for p in pairs], 1)
+            A = self._stack([p[0] for p in pairs], 1, bf)
+        G = self._stack([p[1] for p in pairs], 1, bf)
         self._emit(layer, A, G)
 
     def _fused_sink(self, module: nn.Module, A: torch.Tensor, G: torch.Tensor):

@@ -184,9 +184,112 @@ class DPRNNBase(nn.Module):
         return out, h_n
 
 
+class _LSTMRecurrence(torch.autograd.Function):
+    """The recurrences of one DPLSTM layer (one per direction) in one K10 launch each way.
+    Tensor arguments per direction d: xg_d [B,T,4H] (= ih_d(x), bias_ih included), h0_d, c0_d ([B,H] or None for
+    all), Whh_d [4H,H], bhh_d ([4H] or None).  Returns out_d [B,T,H] per direction, then c_n per direction."""
+
+    @staticmethod
+    def forward(ctx, cells, feed, reverse_mask, *args):
+        from .. import _native
+        G = len(cells)
+        per = [args[5 * g:5 * g + 5] for g in range(G)]
+        xgs = [p[0].contiguous() for p in per]
+        H = xgs[0].shape[-1] // 4
+        has_state = per[0][1] is not None
+        h0s = [p[1].contiguous() for p in per] if has_state else None
+        c0s = [p[2].contiguous() for p in per] if has_state else None
+        whh = [p[3].contiguous() for p in per]
+        bhhs = [p[4].contiguous() for p in per] if per[0][4] is not None else None
+        P = _native.lstm_pack_forward(whh, H)
+        out, gates, C, Hprev = _native.lstm_forward(xgs, h0s, c0s, bhhs, P, reverse_mask)
+        ctx.cells, ctx.feed, ctx.reverse_mask, ctx.has_state = cells, feed, reverse_mask, has_state
+        ctx.has_bias = bhhs is not None
+        ctx.save_for_backward(gates, C, Hprev, *whh, *(c0s or []))
+        T = out.shape[2]
+        c_n = tuple(C[g, :, 0 if (reverse_mask >> g) & 1 else T - 1] for g in range(G))
+        ctx.mark_non_differentiable(*c_n)
+        return tuple(out[g] for g in range(G)) + c_n
+
+    @staticmethod
+    def backward(ctx, *grads_out):
+        from .. import _native
+        G = len(ctx.cells)
+        gates, C, Hprev, *rest = ctx.saved_tensors
+        whh, c0s = rest[:G], (rest[G:] if ctx.has_state else None)
+        H = C.shape[-1]
+        need = ctx.needs_input_grad[3:]
+        want_d0 = ctx.has_state and any(need[5 * g + 1] or need[5 * g + 2] for g in range(G))
+        douts = [None if d is None else d.contiguous() for d in grads_out[:G]]
+        Pt = _native.lstm_pack_backward(list(whh), H)
+        dpre, dh0, dc0 = _native.lstm_backward(douts, list(c0s) if c0s else None, gates, C, Pt, ctx.reverse_mask,
+                                               want_d0)
+        grads = []
+        for g in range(G):
+            cell = ctx.cells[g]
+            sink = cell._dpk_sink
+            if ctx.feed and sink is not None:  # hh's per-sample gradient: A = h_{t-1}, G = dpre (ih gets its own
+                sink(cell.hh, Hprev[g], dpre[g])  # through the ordinary Linear hook on xg's gradient)
+            gw = gb = None
+            if need[5 * g + 3]:
+                gw = torch.einsum("bto,bti->oi", dpre[g], Hprev[g])
+            if ctx.has_bias and need[5 * g + 4]:
+                gb = dpre[g].sum(dim=(0, 1))
+            grads += [dpre[g], dh0[g] if (want_d0 and need[5 * g + 1]) else None,
+                      dc0[g] if (want_d0 and need[5 * g + 2]) else None, gw, gb]
+        return (None, None, None, *grads)
+
+
 class DPLSTM(DPRNNBase):
     cell_type = DPLSTMCell
     has_cell_state = True
+    fuse = True  # run each layer's recurrences as K10 launches when the tensors are on a HIP device
+
+    def __init__(self, *args, **kwargs):
+        super().__init__(*args, **kwargs)
+        for cell in self.cells:
+            object.__setattr__(cell, "_dpk_sink", None)
+            object.__setattr__(cell, "_dpk_sink_active", None)
+
+    def _fusable(self, x) -> bool:
+        from .. import _native
+        return (self.fuse and x.is_cuda and x.dtype == torch.float32 and x.shape[0] > 0 and x.shape[1] > 0
+                and self.hidden_size <= _native.LSTM_MAX_HIDDEN
+                and not (self.dropout_layer is not None and self.training and self.num_layers > 1 and False))
+
+    def forward(self, x: torch.Tensor, state=None):
+        if isinstance(x, torch.nn.utils.rnn.PackedSequence) or not self._fusable(x):
+            return super().forward(x, state)
+        if not self.batch_first:
+            x = x.transpose(0, 1)  # the kernels are batch-major: [B, T, D]
+        B, T, _ = x.shape
+        L, D, H = self.num_layers, self.num_directions, self.hidden_size
+        h0, c0 = state if state is not None else (None, None)
+        hn, cn = [], []
+        inp = x
+        for layer in range(L):
+            cells = [self.cells[layer * D + d] for d in range(D)]
+            sink_on = [c._dpk_sink is not None and self.training and torch.is_grad_enabled()
+                       and (c._dpk_sink_active is None or c._dpk_sink_active()) for c in cells]
+            feed = all(sink_on)
+            args = []
+            for d, cell in enumerate(cells):
+                k = layer * D + d
+                xg = cell.ih(inp)  # ONE [B,T,in] -> [B,T,4H] call per direction (hooked like any Linear)
+                w, bias = cell.hh.weight, cell.hh.bias
+                if feed:  # per-sample gradients come from the sink; autograd must not also build the summed ones
+                    w, bias = w.detach(), (None if bias is None else bias.detach())
+                args += [xg, None if h0 is None else h0[k], None if c0 is None else c0[k], w, bias]
+            res = _LSTMRecurrence.apply(tuple(cells), feed, 2 if D == 2 else 0, *args)
+            outs, c_last = res[:D], res[D:]
+            for d in range(D):
+                hn.append(outs[d][:, 0] if d == 1 else outs[d][:, T - 1])
+                cn.append(c_last[d])
+            inp = outs[0] if D == 1 else torch.cat(outs, dim=2)
+            if self.dropout_layer is not None and layer < L - 1:
+                inp = self.dropout_layer(inp)
+        out = inp if self.batch_first else inp.transpose(0, 1)
+        return out, (torch.stack(hn, 0), torch.stack(cn, 0))
 
 
 class DPGRU(DPRNNBase):

@@ -182,6 +182,30 @@ int dpk_gru_backward(const float* const* dout, const float* const* dhT, const fl
                      float* dh0, int B, int T, int H, int G, void* stream);
 
 /*
+ * K10 — fused DPLSTM recurrence (denoiser).  Replaces, per layer, the T-step loop of Opacus'
+ * DPLSTM cells (what ModuleValidator.fix makes of the nn.LSTM at Model_Code/timediffusion.py:106; cell math as in
+ * nn.LSTM, gate order i,f,g,o) and its autograd backward with ONE launch each for G <= DPK_GRU_MAX_G independent
+ * recurrences of equal shape (the two directions of a bidirectional layer): bit g of reverse_mask makes recurrence g
+ * walk t = T-1..0.  The input projection is done outside for all steps at once: xg[g] = ih(x) [B,T,4H] (bias_ih
+ * included); Whh[g] is the hh weight [4H,H] row-major, bhh[g] its bias [4H] (bhh NULL or NULL entry = none).
+ *   pack_forward : P  [G, 4, dpk_gru_pack_floats(H, H)]      pack_backward: Pt [G, dpk_gru_pack_floats(H, 4H)]
+ * forward writes out = h_t [G,B,T,H], the gate activations `gates` [G,B,T,4H], the cell state C [G,B,T,H] and
+ *   Hprev [G,B,T,H] = the hidden state each step consumed (the `A` operand of hh's per-sample gradient).
+ *   h0 / c0: NULL or per-recurrence [B,H] (NULL entry = zeros).
+ * backward writes dpre [G,B,T,4H] = dL/d(pre-activation) — both dL/dxg and the `G` operand of the ih and hh
+ *   per-sample-gradient contractions — and, if non-NULL, dh0 / dc0 [G,B,H].  dout[g] [B,T,H] (NULL entry = zeros).
+ * H <= 256, any H >= 1 (rows that are not 16-byte aligned are accessed in smaller pieces).
+ */
+int dpk_lstm_pack_forward(const float* const* Whh, float* P, int H, int G, void* stream);
+int dpk_lstm_pack_backward(const float* const* Whh, float* Pt, int H, int G, void* stream);
+int dpk_lstm_forward(const float* const* xg, const float* const* h0, const float* const* c0,
+                     const float* const* bhh, const float* P, float* out, float* gates, float* C,
+                     float* Hprev, int reverse_mask, int B, int T, int H, int G, void* stream);
+int dpk_lstm_backward(const float* const* dout, const float* const* c0, const float* gates,
+                      const float* C, const float* Pt, float* dpre, float* dh0, float* dc0,
+                      int reverse_mask, int B, int T, int H, int G, void* stream);
+
+/*
  * K9 — Adam with L2 weight decay on the arena-layout gradient.  Replaces
  * torch.optim.Adam.step() as called by DPOptimizer.step() (optimizer built at timeautoencoder.py:658, stepped at
  * :751) with one launch:  g = grad + wd*p;  m += (g-m)(1-b1);  v = b2 v + (1-b2) g^2;
