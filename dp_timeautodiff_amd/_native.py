@@ -15,7 +15,7 @@ import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_NAME = "libdpk_gfx950.so"
-LIB_PATH = os.path.join(_HERE, LIB_NAME)
+LIB_PATH = os.environ.get("DPK_LIB_PATH") or os.path.join(_HERE, LIB_NAME)  # override: lab builds only
 
 EXPORTS = {
     # name: (restype, argtypes)

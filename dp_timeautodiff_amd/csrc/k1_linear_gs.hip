@@ -26,6 +26,10 @@
 namespace {
 
 constexpr int TK = 32;  // time steps staged per LDS chunk (even)
+#ifndef DPK_K1_STREAM_MAX_T
+#define DPK_K1_STREAM_MAX_T 32
+#endif
+constexpr int STREAM_MAX_T = DPK_K1_STREAM_MAX_T;  // longest sequence kept whole in LDS (single-chunk streaming mode)
 
 template <int W, int NTHR>
 __device__ __forceinline__ void stage_rows(float* __restrict__ s, const float* __restrict__ g, int t0, int rows,
@@ -215,6 +219,9 @@ inline Plan pick_plan(int in_f, int out_f) {
     if (in_f <= 32) return Plan{4, 128, 32};
     if (in_f <= 64) return Plan{2, 128, 64};
     if (in_f <= 128) return Plan{1, 128, 128};
+#ifdef DPK_K1_NO_PLAN0
+    return Plan{1, 128, 128};
+#endif
     return Plan{0, 128, 256};
 }
 
@@ -248,19 +255,24 @@ extern "C" int dpk_linear_grad_sample(const float* A, const float* G, float* GSw
     const int nt_store = (ld_w % 32 == 0) && (gs_stride % 32 == 0) && ((((uintptr_t)GSw) & 127u) == 0);
     hipStream_t s = (hipStream_t)stream;
     dim3 grid((unsigned)nblk);
-    const bool stream_mode = T <= TK;
+    const bool stream_mode = T <= STREAM_MAX_T;
     const int lds_rows = stream_mode ? ((T + 1) & ~1) : TK;
 #define DPK_K1_GO(NW, RS, CS, NT, ST, NTS)                                                                       \
+    if (lds > 64 * 1024) {                                                                                       \
+        hipError_t e_ = hipFuncSetAttribute((const void*)linear_gs_kernel<NW, RS, CS, NT, ST, NTS>,              \
+                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);               \
+        if (e_ != hipSuccess) return (int)e_;                                                                    \
+    }                                                                                                            \
     hipLaunchKernelGGL((linear_gs_kernel<NW, RS, CS, NT, ST, NTS>), grid, dim3(NW * 64), lds, s, A, G, GSw, GSb,  \
                        normsq_part, part_stride, slot0, B, T, in_f, out_f, gs_stride, ld_w, g_scale, tiles_m,    \
                        tiles_n, vecA, vecG)
 #define DPK_K1_LAUNCH(NW, RS, CS, NT)                                                                          \
     do {                                                                                                       \
         const size_t lds = ((size_t)lds_rows * (RS + CS) + NW) * sizeof(float);                                \
-        if (stream_mode && nt_store) DPK_K1_GO(NW, RS, CS, NT, true, true);                                    \
-        else if (stream_mode) DPK_K1_GO(NW, RS, CS, NT, true, false);                                          \
-        else if (nt_store) DPK_K1_GO(NW, RS, CS, NT, false, true);                                             \
-        else DPK_K1_GO(NW, RS, CS, NT, false, false);                                                          \
+        if (stream_mode && nt_store) { DPK_K1_GO(NW, RS, CS, NT, true, true); }                                \
+        else if (stream_mode) { DPK_K1_GO(NW, RS, CS, NT, true, false); }                                      \
+        else if (nt_store) { DPK_K1_GO(NW, RS, CS, NT, false, true); }                                         \
+        else { DPK_K1_GO(NW, RS, CS, NT, false, false); }                                                      \
     } while (0)
     switch (p.id) {
         case 0: DPK_K1_LAUNCH(8, 128, 256, 2); break;
