@@ -143,7 +143,7 @@ def main():
     wl = workloads.build(args.config, dev, batch=args.batch, seed_offset=rank * 1000,
                          fuse_recurrence=not args.hooked_gru)
     B = wl.B
-    phys = args.physical_batch or (512 if args.config == "cfg5" else B)
+    phys = args.physical_batch or (2048 if args.config == "cfg5" else B)  # cfg5: 49 MB/sample -> 100 GB arena
     model = wl.model
     if world > 1:
         DPDDP(model)  # broadcasts rank-0 parameters
