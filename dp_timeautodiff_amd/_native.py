@@ -32,7 +32,9 @@ EXPORTS = {
     "dpk_layernorm_grad_sample": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int,
                                           c_int, c_int, c_int, c_float, c_int64, c_float, c_void_p]),
     "dpk_normsq_partials": (c_int, [c_void_p, c_int64, c_void_p, c_int64, c_int, c_int, c_int64, c_void_p]),
-    "dpk_clip_factors": (c_int, [c_void_p, c_int64, c_int, c_void_p, c_void_p, c_int, c_float, c_void_p]),
+    "dpk_clip_factors": (c_int, [c_void_p, c_int64, c_int, c_void_p, c_void_p, c_int, c_float, c_void_p, c_void_p]),
+    "dpk_poisson_sample": (c_int, [c_uint64, c_uint64, c_void_p, c_float, c_int64, c_int, c_void_p, c_void_p,
+                                   c_void_p]),
     "dpk_clip_reduce_workspace": (c_int64, [c_int, c_int64]),
     "dpk_clip_reduce": (c_int, [c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_int, c_int64, c_void_p,
                                 c_int64, c_void_p]),
@@ -197,12 +199,14 @@ def normsq_partials(gs: FlatView, B: int, part: torch.Tensor, slot0: int):
 
 
 def clip_factors(part: torch.Tensor, n_slots: int, clip: torch.Tensor, norms: Optional[torch.Tensor], B: int,
-                 max_grad_norm: float):
+                 max_grad_norm: float, n_valid_dev: Optional[torch.Tensor] = None):
     _req(part, "normsq_part"); _req(clip, "clip")
+    if n_valid_dev is not None:
+        _req(n_valid_dev, "n_valid", torch.int32)
     if part.shape[0] < B or clip.numel() < B or (norms is not None and norms.numel() < B) or n_slots > part.shape[1]:
         raise DpkError("clip_factors: buffers shorter than the batch / slots")
     rc = load().dpk_clip_factors(_ptr(part), part.stride(0), n_slots, _ptr(clip), _ptr(norms), B,
-                                 float(max_grad_norm), _stream())
+                                 float(max_grad_norm), _ptr(n_valid_dev), _stream())
     _check(rc, "dpk_clip_factors")
 
 
@@ -463,3 +467,17 @@ def adam_step(grad, exp_avg, exp_avg_sq, win_table, hyper, step_dev, P: int):
     rc = load().dpk_adam_step(_ptr(grad), _ptr(exp_avg), _ptr(exp_avg_sq), _ptr(win_table), _ptr(hyper), n,
                               _ptr(step_dev), P, _stream())
     _check(rc, "dpk_adam_step")
+
+
+# ---- K11: on-device Poisson sampler -------------------------------------------------------------------------------
+
+
+def poisson_sample(seed: int, offset: int, sample_rate: float, N: int, idx: torch.Tensor, counts: torch.Tensor,
+                   offset_dev: Optional[torch.Tensor] = None):
+    """idx: int64 [capacity] (selected indices, ascending, padded with 0); counts: int32 [2] = (n kept, n selected)."""
+    _req(idx, "idx", torch.int64); _req(counts, "counts", torch.int32)
+    if not idx.is_contiguous() or counts.numel() != 2 or idx.numel() == 0:
+        raise DpkError("poisson_sample: idx must be a contiguous int64 vector, counts int32[2]")
+    rc = load().dpk_poisson_sample(seed & (2**64 - 1), offset & (2**64 - 1), _ptr(offset_dev), float(sample_rate),
+                                   int(N), idx.numel(), _ptr(idx), _ptr(counts), _stream())
+    _check(rc, "dpk_poisson_sample")

@@ -14,7 +14,8 @@ from typing import List
 import numpy as np
 from torch.utils.data import BatchSampler, DataLoader, Sampler
 
-from .data_loader import DistributedUniformWithReplacementSampler, UniformWithReplacementSampler
+from .data_loader import (DevicePoissonLoader, DistributedUniformWithReplacementSampler,
+                          UniformWithReplacementSampler)
 
 
 class BatchSplittingSampler(Sampler[List[int]]):
@@ -46,7 +47,32 @@ class BatchSplittingSampler(Sampler[List[int]]):
         return len(self.sampler)
 
 
+class _DeviceChunker:
+    """BatchMemoryManager over a DevicePoissonLoader: each logical (Poisson) batch already sits in HBM and is cut
+    into views of at most `max_batch_size` rows; all but the last chunk signal a skipped optimizer step."""
+
+    def __init__(self, loader: DevicePoissonLoader, max_batch_size: int, optimizer):
+        self.loader, self.max_batch_size, self.optimizer = loader, max_batch_size, optimizer
+
+    def __len__(self):
+        return len(self.loader)
+
+    @property
+    def dataset(self):
+        return self.loader.dataset
+
+    def __iter__(self):
+        for batch in self.loader:
+            n = batch[0].shape[0]
+            bounds = list(range(0, n, self.max_batch_size)) or [0]
+            for i, lo in enumerate(bounds):
+                self.optimizer.signal_skip_step(do_skip=i < len(bounds) - 1)
+                yield [t[lo:lo + self.max_batch_size] for t in batch]
+
+
 def wrap_data_loader(*, data_loader: DataLoader, max_batch_size: int, optimizer):
+    if isinstance(data_loader, DevicePoissonLoader):
+        return _DeviceChunker(data_loader, max_batch_size, optimizer)
     return DataLoader(
         dataset=data_loader.dataset,
         batch_sampler=BatchSplittingSampler(sampler=data_loader.batch_sampler, max_batch_size=max_batch_size,

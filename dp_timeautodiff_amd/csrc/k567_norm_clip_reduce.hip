@@ -43,9 +43,17 @@ __global__ void __launch_bounds__(256) normsq_kernel(const float* __restrict__ G
 // one wave per sample: lane l sums slots l, l+64, ... in order, then a fixed butterfly
 __global__ void __launch_bounds__(256) clip_factor_kernel(const float* __restrict__ part, int64_t part_stride,
                                                           int n_slots, float* __restrict__ clip,
-                                                          float* __restrict__ norms, int B, float max_grad_norm) {
+                                                          float* __restrict__ norms, int B, float max_grad_norm,
+                                                          const int* __restrict__ n_valid_dev) {
     const int b = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (b >= B) return;
+    if (n_valid_dev && b >= *n_valid_dev) {  // padding row of a fixed-capacity Poisson batch: contributes nothing
+        if ((threadIdx.x & 63) == 0) {
+            clip[b] = 0.f;
+            if (norms) norms[b] = 0.f;
+        }
+        return;
+    }
     const int lane = threadIdx.x & 63;
     const float* row = part + (int64_t)b * part_stride;
     float s = 0.f;
@@ -237,11 +245,11 @@ extern "C" int dpk_normsq_partials(const float* GS, int64_t gs_stride, float* no
 }
 
 extern "C" int dpk_clip_factors(const float* normsq_part, int64_t part_stride, int n_slots, float* clip,
-                                float* norms, int B, float max_grad_norm, void* stream) {
+                                float* norms, int B, float max_grad_norm, const int* n_valid_dev, void* stream) {
     if (!normsq_part || !clip || B < 0 || n_slots < 0 || n_slots > part_stride) return DPK_EINVAL;
     if (B == 0) return DPK_OK;
     hipLaunchKernelGGL(clip_factor_kernel, dim3((unsigned)((B + 3) / 4)), dim3(256), 0, (hipStream_t)stream,
-                       normsq_part, part_stride, n_slots, clip, norms, B, max_grad_norm);
+                       normsq_part, part_stride, n_slots, clip, norms, B, max_grad_norm, n_valid_dev);
     return dpk_launch_status();
 }
 

@@ -176,3 +176,82 @@ def switch_generator(*, data_loader: DataLoader, generator):
         timeout=data_loader.timeout, worker_init_fn=data_loader.worker_init_fn,
         multiprocessing_context=data_loader.multiprocessing_context, generator=generator,
         prefetch_factor=data_loader.prefetch_factor, persistent_workers=data_loader.persistent_workers)
+
+
+class DevicePoissonLoader:
+    """Poisson-sampled batches drawn, compacted and gathered on the GPU (K11).
+
+    Stands where `DPDataLoader.from_data_loader(...)` stands for a `TensorDataset` (what the reference builds at
+    Model_Code/timeautoencoder.py:664-670): the dataset tensors live in HBM, each step `dpk_poisson_sample` selects
+    every sample independently with probability `sample_rate` from a Philox stream and `index_select` gathers the
+    rows — no per-sample Python collation, no host-to-device copy.
+
+    Two ways to consume it:
+      * `for batch in loader:` — drop-in for the reference loop: yields a list of tensors with exactly the n
+        selected rows (n is read back, one host sync per step), `len(loader)` = int(1 / sample_rate) steps;
+      * `loader.sample_static()` — shape-static: returns the SAME `[capacity, ...]` tensors every call plus a device
+        int32 `n_valid`; rows >= n_valid are padding (copies of sample 0) that `DPOptimizer.set_valid_rows(n_valid)`
+        masks out with clip factor 0.  This is the form a hipGraph-captured step replays.
+    `capacity` defaults to expected + 8 sigma + 8 (overflow probability < 1e-14 per step); `overflow_steps()`
+    reports if a draw ever exceeded it (the excess samples of that step were dropped).
+    """
+
+    def __init__(self, tensors, *, sample_rate: float, device=None, capacity: Optional[int] = None,
+                 seed: Optional[int] = None, steps: Optional[int] = None):
+        from . import _native
+        self._native = _native
+        tensors = list(tensors)
+        if not tensors or any(t.shape[0] != tensors[0].shape[0] for t in tensors):
+            raise ValueError("DevicePoissonLoader needs tensors with a common first dimension")
+        device = torch.device(device) if device is not None else tensors[0].device
+        if device.type != "cuda":
+            raise _native.DpkError("DevicePoissonLoader samples on a HIP device; there is no CPU path")
+        self.tensors = [t.to(device).contiguous() for t in tensors]
+        self.num_samples = self.tensors[0].shape[0]
+        self.sample_rate = float(sample_rate)
+        self.steps = steps if steps is not None else int(1 / self.sample_rate)
+        exp = self.num_samples * self.sample_rate
+        if capacity is None:
+            capacity = int(exp + 8.0 * (exp * (1.0 - self.sample_rate)) ** 0.5 + 8)
+        self.capacity = max(1, min(int(capacity), self.num_samples))
+        import os
+        self.seed = int.from_bytes(os.urandom(8), "little") if seed is None else int(seed)
+        self.device = device
+        self._blocks_per_draw = (self.num_samples + 3) // 4
+        self._offset_dev = torch.zeros(1, dtype=torch.int64, device=device)  # advanced on device: graph-replayable
+        self.idx = torch.zeros(self.capacity, dtype=torch.int64, device=device)
+        self.counts = torch.zeros(2, dtype=torch.int32, device=device)
+        self.n_valid = self.counts[0:1]
+        self._overflow = torch.zeros(1, dtype=torch.int64, device=device)
+        self._static = [torch.empty((self.capacity,) + tuple(t.shape[1:]), dtype=t.dtype, device=device)
+                        for t in self.tensors]
+        self.dataset = torch.utils.data.TensorDataset(*self.tensors)  # PrivacyEngine reads len(loader.dataset)
+
+    @classmethod
+    def from_data_loader(cls, data_loader: DataLoader, *, device, seed: Optional[int] = None, capacity=None):
+        ds = data_loader.dataset
+        if not isinstance(ds, torch.utils.data.TensorDataset):
+            raise ValueError("DevicePoissonLoader needs a TensorDataset (tensors that can live in HBM)")
+        return cls(ds.tensors, sample_rate=1 / len(data_loader), device=device, seed=seed, capacity=capacity)
+
+    def __len__(self):
+        return self.steps
+
+    def sample_static(self):
+        """One Poisson draw into the static batch tensors (all device-side; capturable into a hipGraph)."""
+        self._native.poisson_sample(self.seed, 0, self.sample_rate, self.num_samples, self.idx, self.counts,
+                                    offset_dev=self._offset_dev)
+        self._offset_dev.add_(self._blocks_per_draw)
+        self._overflow.add_((self.counts[1] > self.capacity).to(torch.int64))
+        for dst, src in zip(self._static, self.tensors):
+            torch.index_select(src, 0, self.idx, out=dst)
+        return self._static, self.n_valid
+
+    def overflow_steps(self) -> int:
+        return int(self._overflow.item())
+
+    def __iter__(self):
+        for _ in range(self.steps):
+            static, _ = self.sample_static()
+            n = int(self.counts[0].item())
+            yield [t[:n] for t in static]

@@ -34,24 +34,34 @@ def _make_capturable(optimizer: torch.optim.Optimizer):
 
 
 class GraphedDPStep:
-    def __init__(self, module: GradSampleModule, optimizer: DPOptimizer, loss_fn: Callable[[], torch.Tensor],
-                 warmup: int = 3):
-        """`loss_fn()` runs forward + loss on STATIC device tensors and returns the scalar loss."""
+    def __init__(self, module: GradSampleModule, optimizer: DPOptimizer, loss_fn: Callable[..., torch.Tensor],
+                 warmup: int = 3, loader=None):
+        """`loss_fn()` runs forward + loss on STATIC device tensors and returns the scalar loss.
+        With `loader` (a DevicePoissonLoader) every step first draws a Poisson batch on the device into the loader's
+        static `[capacity, ...]` tensors and calls `loss_fn(batch_tensors)`; the padding rows are masked by K6."""
         if not isinstance(module, GradSampleModule) or not isinstance(optimizer, DPOptimizer):
             raise TypeError("GraphedDPStep needs the GradSampleModule and DPOptimizer returned by PrivacyEngine")
         self.module, self.optimizer, self.loss_fn = module, optimizer, loss_fn
         self.graph: Optional[torch.cuda.CUDAGraph] = None
         self.static_loss: Optional[torch.Tensor] = None
         self.warmup = warmup
+        self.loader = loader
         self.replays = 0
         # data-parallel: only the communication-free part is captured; the flat all-reduce, the shared-noise
         # kernel and the wrapped optimizer run eagerly after each replay (4-15 launches)
         self.distributed = isinstance(optimizer, DistributedDPOptimizer)
 
+    def _loss(self):
+        if self.loader is None:
+            return self.loss_fn()
+        batch, n_valid = self.loader.sample_static()
+        self.optimizer.set_valid_rows(n_valid)
+        return self.loss_fn(batch)
+
     def _eager_step(self):
         opt = self.optimizer
         opt.zero_grad(set_to_none=True)
-        loss = self.loss_fn()
+        loss = self._loss()
         loss.backward()
         opt.step()
         return loss.detach()
@@ -59,7 +69,7 @@ class GraphedDPStep:
     def _local_part(self):
         opt = self.optimizer
         opt.zero_grad(set_to_none=True)
-        loss = self.loss_fn()
+        loss = self._loss()
         loss.backward()
         opt.local_step()
         return loss.detach()

@@ -65,6 +65,7 @@ class DPOptimizer(Optimizer):
         self._injected_noise: Optional[torch.Tensor] = None
         self._arena = None
         self._gsm = None
+        self._n_valid_dev: Optional[torch.Tensor] = None  # device int32: real rows of a fixed-capacity Poisson batch
         for p in self.params:
             p.summed_grad = None
 
@@ -147,9 +148,15 @@ class DPOptimizer(Optimizer):
                              "zero_grad() before the next backward pass")
         return arena, arena.rows
 
+    def set_valid_rows(self, n_valid_dev: Optional[torch.Tensor]):
+        """Rows >= n_valid_dev[0] (a device int32) of the next batches are padding (DevicePoissonLoader's
+        fixed-capacity batches): K6 gives them clip factor 0.  None = every row is real."""
+        self._n_valid_dev = n_valid_dev
+
     def _clip_factors(self, arena, B):
         if B > 0:
-            _native.clip_factors(arena.part, arena.n_slots, arena.clip, arena.norms, B, self.max_grad_norm)
+            _native.clip_factors(arena.part, arena.n_slots, arena.clip, arena.norms, B, self.max_grad_norm,
+                                 n_valid_dev=self._n_valid_dev)
 
     def clip_and_accumulate(self):
         """K6 + K7a: p.summed_grad (+)= sum_b clip_b * grad_sample_b  — one pass over the arena."""

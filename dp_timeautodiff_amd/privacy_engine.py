@@ -22,7 +22,7 @@ from torch.utils.data import DataLoader
 
 from .accountants import create_accountant
 from .accountants.utils import get_noise_multiplier
-from .data_loader import DPDataLoader, switch_generator
+from .data_loader import DevicePoissonLoader, DPDataLoader, switch_generator
 from .distributed import DifferentiallyPrivateDistributedDataParallel as DPDDP
 from .grad_sample import GradSampleModule
 from .layers.fused_gru import fuse_recurrences
@@ -59,7 +59,7 @@ class PrivacyEngine:
                    generator=noise_generator, secure_mode=self.secure_mode, noise_seed=noise_seed, **kwargs)
 
     def _prepare_data_loader(self, data_loader: DataLoader, *, poisson_sampling: bool,
-                             distributed: bool) -> DataLoader:
+                             distributed: bool, device_sampler_on=None) -> DataLoader:
         if self.dataset is None:
             self.dataset = data_loader.dataset
         elif self.dataset != data_loader.dataset:
@@ -67,6 +67,12 @@ class PrivacyEngine:
                           f"{data_loader.dataset}. Privacy accounting works per dataset, please initialize new "
                           "PrivacyEngine if you're using different dataset. You can ignore this warning if two "
                           "datasets above represent the same logical dataset")
+        if poisson_sampling and device_sampler_on is not None:
+            if distributed:
+                raise NotImplementedError("device_sampler=True is single-process for now; shard the TensorDataset "
+                                          "per rank and build a DevicePoissonLoader on each")
+            # K11: Bernoulli draws, compaction and the row gather all happen in HBM (no per-sample collation)
+            return DevicePoissonLoader.from_data_loader(data_loader, device=device_sampler_on)
         if poisson_sampling:
             return DPDataLoader.from_data_loader(data_loader, generator=self.secure_rng, distributed=distributed)
         elif self.secure_mode:
@@ -117,6 +123,7 @@ class PrivacyEngine:
         if noise_generator and self.secure_mode:
             raise ValueError("Passing seed is prohibited in secure mode")
         self.fuse_recurrence = bool(kwargs.pop("fuse_recurrence", getattr(self, "fuse_recurrence", True)))
+        device_sampler = bool(kwargs.pop("device_sampler", False))
 
         # compare module parameter with optimizer parameters
         model_parameters = set(module.parameters())
@@ -134,8 +141,9 @@ class PrivacyEngine:
         if poisson_sampling:
             module.forbid_grad_accumulation = True
 
+        dev_on = next(module.parameters()).device if device_sampler else None
         data_loader = self._prepare_data_loader(data_loader, distributed=distributed,
-                                                poisson_sampling=poisson_sampling)
+                                                poisson_sampling=poisson_sampling, device_sampler_on=dev_on)
 
         sample_rate = 1 / len(data_loader)
         expected_batch_size = int(len(data_loader.dataset) * sample_rate)

@@ -101,9 +101,11 @@ int dpk_normsq_partials(const float* GS, int64_t gs_stride, float* normsq_part, 
  *     per_sample_clip_factor = (max_grad_norm / (per_sample_norms + 1e-6)).clamp(max=1.0)
  * normsq_part [B, part_stride]: slots [0, n_slots) of each row are summed in index order.
  * norms (nullable) receives sqrt(sum); clip receives the factor.
+ * n_valid_dev (nullable) points at a DEVICE int: rows b >= *n_valid_dev are the padding of a fixed-capacity Poisson
+ * batch (dpk_poisson_sample) and get clip = 0, norm = 0, so they add nothing to the clipped sum.
  */
 int dpk_clip_factors(const float* normsq_part, int64_t part_stride, int n_slots,
-                     float* clip, float* norms, int B, float max_grad_norm, void* stream);
+                     float* clip, float* norms, int B, float max_grad_norm, const int* n_valid_dev, void* stream);
 
 /*
  * K7a — clipped weighted sum over the batch.  Replaces  einsum("i,i...", clip, grad_sample)  per
@@ -180,6 +182,18 @@ int dpk_gru_backward(const float* const* dout, const float* const* dhT, const fl
                      const float* N, const float* Azr, const float* Pnx, const float* Pnh,
                      const float* Pzrx, const float* Pzrh, float* dxp, float* Gz, float* Gr, float* Gn,
                      float* dh0, int B, int T, int H, int G, void* stream);
+
+/*
+ * K11 — on-device Poisson sampler.  Replaces the host side of Opacus' DPDataLoader /
+ * UniformWithReplacementSampler as the reference reaches it through make_private_with_epsilon
+ * (timeautoencoder.py:664-682, consumed at :726-733): `mask = rand(N) < sample_rate; idx = mask.nonzero()`.
+ * Sample j is selected iff u_j < sample_rate, u_j = ((x >> 8) + 0.5) * 2^-24 with x = word (j & 3) of Philox4x32-10
+ * block (offset + *offset_dev + j / 4) under key `seed`; the selected indices are written in increasing order to
+ * idx[0..n), idx[n..capacity) is padded with 0, counts[0] = min(n_selected, capacity), counts[1] = n_selected.
+ * A call consumes ceil(N / 4) Philox blocks.  idx: device int64[capacity]; counts: device int[2].
+ */
+int dpk_poisson_sample(uint64_t seed, uint64_t offset, const uint64_t* offset_dev, float sample_rate,
+                       int64_t N, int capacity, int64_t* idx, int* counts, void* stream);
 
 /*
  * K10 — fused DPLSTM recurrence (denoiser).  Replaces, per layer, the T-step loop of Opacus'

@@ -303,3 +303,19 @@ class OracleDPOptimizer:
         for p, g in zip(self.params, grads):
             p.grad = g.view_as(p)
         return True
+
+
+def poisson_select(N: int, sample_rate: float, seed: int, offset: int) -> np.ndarray:
+    """Indices a Poisson draw selects: j is in iff u_j < sample_rate (float32 compare), u_j = word (j & 3) of Philox
+    block (offset + j // 4) mapped to (0,1) as in philox_normal.  Restates Opacus' UniformWithReplacementSampler
+    (`(rand(N) < sample_rate).nonzero()`) on the counter-based stream of dpk_poisson_sample."""
+    nblk = (N + 3) // 4
+    blk = np.arange(nblk, dtype=np.uint64) + np.uint64(offset)
+    ctr = np.zeros((nblk, 4), np.uint32)
+    ctr[:, 0] = (blk & np.uint64(0xFFFFFFFF)).astype(np.uint32)
+    ctr[:, 1] = (blk >> np.uint64(32)).astype(np.uint32)
+    key = np.array([seed & 0xFFFFFFFF, (seed >> 32) & 0xFFFFFFFF], np.uint32)
+    x = philox4x32_10(ctr, key)
+    u = ((x >> np.uint32(8)).astype(np.float32) + np.float32(0.5)) * np.float32(2.0 ** -24)
+    mask = (u.reshape(-1)[:N] < np.float32(sample_rate))
+    return np.nonzero(mask)[0].astype(np.int64)

@@ -59,13 +59,18 @@ def layernorm_grad_sample(X, G, gs_w, gs_b, part, slot0, eps, g_scale):
     part[:B, slot0] = (gw ** 2).sum(1) + (gb ** 2).sum(1)
 
 
-def clip_factors(part, n_slots, clip, norms, B, max_grad_norm):
+def clip_factors(part, n_slots, clip, norms, B, max_grad_norm, n_valid_dev=None):
     if B == 0:
         return
     n = part[:B, :n_slots].sum(1).sqrt()
+    c = (max_grad_norm / (n + 1e-6)).clamp(max=1.0)
+    if n_valid_dev is not None:
+        pad = torch.arange(B) >= int(n_valid_dev)
+        n = n.masked_fill(pad, 0.0)
+        c = c.masked_fill(pad, 0.0)
     if norms is not None:
         norms[:B] = n
-    clip[:B] = (max_grad_norm / (n + 1e-6)).clamp(max=1.0)
+    clip[:B] = c
 
 
 def clip_reduce_workspace(B, P):

@@ -105,3 +105,18 @@ def test_deapstack_needs_no_fix_and_param_inventory():
     assert ModuleValidator.is_valid(d)
     m2 = models.DeapStackDP(64, 1024, 24, 0, 0, 32, [], 32, 128, 1, 128, 8, 7)
     assert sum(p.numel() for p in m2.parameters()) == 824398
+
+
+def test_oracle_poisson_select_is_a_bernoulli_draw_per_sample():
+    from oracle import opacus_ref as O
+    N, q = 200000, 0.01
+    a = O.poisson_select(N, q, seed=5, offset=0)
+    assert np.array_equal(a, O.poisson_select(N, q, seed=5, offset=0))          # counter-based: reproducible
+    assert not np.array_equal(a, O.poisson_select(N, q, seed=5, offset=N // 4))  # next draw of the stream
+    assert (np.diff(a) > 0).all() and a.min() >= 0 and a.max() < N
+    assert abs(len(a) - N * q) < 6 * (N * q * (1 - q)) ** 0.5
+    # consecutive draws tile the stream: draw k uses blocks [k*ceil(N/4), (k+1)*ceil(N/4))
+    b = O.poisson_select(8, 0.5, seed=1, offset=2)
+    c = O.poisson_select(16, 0.5, seed=1, offset=0)
+    assert np.array_equal(b, c[c >= 8] - 8)
+    assert len(O.poisson_select(64, 0.0, 1, 0)) == 0 and len(O.poisson_select(64, 1.0, 1, 0)) == 64
