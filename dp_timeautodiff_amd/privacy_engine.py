@@ -173,6 +173,8 @@ class PrivacyEngine:
             warnings.warn("You're calling make_private_with_epsilon with non-zero privacy budget already spent. "
                           "Returned noise_multiplier assumes zero starting point, so your overall privacy "
                           "budget will be higher.")
+        # options of this engine (not of the sigma search) travel on to make_private
+        engine_kw = {k: kwargs.pop(k) for k in ("device_sampler", "fuse_recurrence", "noise_seed") if k in kwargs}
         return self.make_private(
             module=module, optimizer=optimizer, data_loader=data_loader,
             noise_multiplier=get_noise_multiplier(target_epsilon=target_epsilon, target_delta=target_delta,
@@ -180,10 +182,15 @@ class PrivacyEngine:
                                                   accountant=self.accountant.mechanism(), **kwargs),
             max_grad_norm=max_grad_norm, batch_first=batch_first, loss_reduction=loss_reduction,
             noise_generator=noise_generator, grad_sample_mode=grad_sample_mode,
-            poisson_sampling=poisson_sampling, clipping=clipping)
+            poisson_sampling=poisson_sampling, clipping=clipping, **engine_kw)
 
     def get_epsilon(self, delta):
-        return self.accountant.get_epsilon(delta)
+        # the reference asks every epoch (timeautoencoder.py:759); PRV's FFT composition is the expensive part of
+        # that call, so the answer is cached per (ledger, delta)
+        key = (repr(getattr(self.accountant, "history", None)), float(delta))
+        if getattr(self, "_eps_cache", (None, None))[0] != key:
+            self._eps_cache = (key, self.accountant.get_epsilon(delta))
+        return self._eps_cache[1]
 
     # ---- checkpoints (unused by the reference; saves what its own save_autoencoder forgets) -----------
     def save_checkpoint(self, *, path: Union[str, os.PathLike, BinaryIO, IO[bytes]],
@@ -197,7 +204,10 @@ class PrivacyEngine:
         checkpoint_dict["privacy_accountant_state_dict"] = self.accountant.state_dict()
         if optimizer is not None:
             checkpoint_dict["optimizer_state_dict"] = optimizer.state_dict()
-            checkpoint_dict["dp_noise_state"] = {"seed": optimizer.noise_seed, "offset": optimizer._noise_offset}
+            dev_off = optimizer._noise_offset_dev  # graph-captured steps keep the Philox offset in a device word
+            checkpoint_dict["dp_noise_state"] = {
+                "seed": optimizer.noise_seed,
+                "offset": int(optimizer._noise_offset) + (int(dev_off.item()) if dev_off is not None else 0)}
         torch.save(checkpoint_dict, path, **(torch_save_kwargs or {}))
 
     def load_checkpoint(self, *, path: Union[str, os.PathLike, BinaryIO, IO[bytes]],
