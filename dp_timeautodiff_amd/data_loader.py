@@ -197,10 +197,17 @@ class DevicePoissonLoader:
     """
 
     def __init__(self, tensors, *, sample_rate: float, device=None, capacity: Optional[int] = None,
-                 seed: Optional[int] = None, steps: Optional[int] = None):
+                 seed: Optional[int] = None, steps: Optional[int] = None, rank: int = 0, world_size: int = 1):
         from . import _native
         self._native = _native
         tensors = list(tensors)
+        if world_size > 1:
+            # data-parallel: rank r owns samples r, r+W, r+2W, ... and draws each of them with the same rate from
+            # its own Philox key.  Independent Bernoulli draws over a fixed partition are exactly a Poisson sample
+            # of the whole dataset (Opacus' DistributedUniformWithReplacementSampler reshuffles the partition every
+            # epoch, which changes nothing in distribution), and no index ever crosses ranks.
+            tensors = [t[rank::world_size] for t in tensors]
+        self.rank, self.world_size = rank, world_size
         if not tensors or any(t.shape[0] != tensors[0].shape[0] for t in tensors):
             raise ValueError("DevicePoissonLoader needs tensors with a common first dimension")
         device = torch.device(device) if device is not None else tensors[0].device
@@ -216,6 +223,7 @@ class DevicePoissonLoader:
         self.capacity = max(1, min(int(capacity), self.num_samples))
         import os
         self.seed = int.from_bytes(os.urandom(8), "little") if seed is None else int(seed)
+        self.seed = (self.seed + 0x9E3779B97F4A7C15 * rank) & (2**64 - 1)  # a distinct stream per rank
         self.device = device
         self._blocks_per_draw = (self.num_samples + 3) // 4
         self._offset_dev = torch.zeros(1, dtype=torch.int64, device=device)  # advanced on device: graph-replayable
@@ -228,11 +236,15 @@ class DevicePoissonLoader:
         self.dataset = torch.utils.data.TensorDataset(*self.tensors)  # PrivacyEngine reads len(loader.dataset)
 
     @classmethod
-    def from_data_loader(cls, data_loader: DataLoader, *, device, seed: Optional[int] = None, capacity=None):
+    def from_data_loader(cls, data_loader: DataLoader, *, device, seed: Optional[int] = None, capacity=None,
+                         rank: int = 0, world_size: int = 1):
         ds = data_loader.dataset
         if not isinstance(ds, torch.utils.data.TensorDataset):
             raise ValueError("DevicePoissonLoader needs a TensorDataset (tensors that can live in HBM)")
-        return cls(ds.tensors, sample_rate=1 / len(data_loader), device=device, seed=seed, capacity=capacity)
+        dl = cls(ds.tensors, sample_rate=1 / len(data_loader), device=device, seed=seed, capacity=capacity,
+                 rank=rank, world_size=world_size)
+        dl.dataset = ds  # PrivacyEngine sizes the expected batch from the WHOLE dataset, then divides by world size
+        return dl
 
     def __len__(self):
         return self.steps

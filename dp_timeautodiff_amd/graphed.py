@@ -94,7 +94,9 @@ class GraphedDPStep:
         hook, opt.step_hook = opt.step_hook, None  # host-side accounting happens per replay, not at capture
         self.graph = torch.cuda.CUDAGraph()
         try:
-            with torch.cuda.graph(self.graph):
+            # thread_local: a collective library's watchdog thread (RCCL) may query events while this thread captures;
+            # in the default "global" mode that would invalidate the capture
+            with torch.cuda.graph(self.graph, capture_error_mode="thread_local"):
                 self.static_loss = self._local_part() if self.distributed else self._eager_step()
         finally:
             opt.step_hook = hook

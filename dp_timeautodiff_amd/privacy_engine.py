@@ -68,11 +68,16 @@ class PrivacyEngine:
                           "PrivacyEngine if you're using different dataset. You can ignore this warning if two "
                           "datasets above represent the same logical dataset")
         if poisson_sampling and device_sampler_on is not None:
-            if distributed:
-                raise NotImplementedError("device_sampler=True is single-process for now; shard the TensorDataset "
-                                          "per rank and build a DevicePoissonLoader on each")
             # K11: Bernoulli draws, compaction and the row gather all happen in HBM (no per-sample collation)
-            return DevicePoissonLoader.from_data_loader(data_loader, device=device_sampler_on)
+            rank = torch.distributed.get_rank() if distributed else 0
+            world = torch.distributed.get_world_size() if distributed else 1
+            seed = None
+            if distributed:  # one base seed for the job (rank 0's); each rank derives its own stream from it
+                t = torch.tensor([int.from_bytes(os.urandom(7), "little")], dtype=torch.int64, device=device_sampler_on)
+                torch.distributed.broadcast(t, src=0)
+                seed = int(t.item())
+            return DevicePoissonLoader.from_data_loader(data_loader, device=device_sampler_on, seed=seed, rank=rank,
+                                                        world_size=world)
         if poisson_sampling:
             return DPDataLoader.from_data_loader(data_loader, generator=self.secure_rng, distributed=distributed)
         elif self.secure_mode:

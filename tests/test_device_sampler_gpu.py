@@ -155,3 +155,20 @@ def test_privacy_engine_device_sampler_and_batch_memory_manager():
             models.vae_loss(gsm, xb).backward()
             dpo.step()
     assert len(real_steps) == 10 and sum(sizes) > 300 and max(sizes) == 32
+
+
+def test_rank_shards_partition_the_dataset_and_draw_independent_streams():
+    from dp_timeautodiff_amd.data_loader import DevicePoissonLoader
+    labels = torch.arange(1001)
+    loaders = [DevicePoissonLoader([labels], sample_rate=0.05, device="cuda", seed=4, rank=r, world_size=3)
+               for r in range(3)]
+    owned = [dl.tensors[0].cpu() for dl in loaders]
+    assert sorted(torch.cat(owned).tolist()) == list(range(1001))  # a partition: no sample on two ranks
+    assert [len(o) for o in owned] == [334, 334, 333]
+    draws = [next(iter(dl))[0].cpu() for dl in loaders]
+    for r, d in enumerate(draws):
+        assert set(d.tolist()) <= set(owned[r].tolist())
+    assert len({dl.seed for dl in loaders}) == 3
+    # pooled over ranks the draw is a Poisson sample of the whole dataset at the same rate
+    n = sum(len(d) for d in draws)
+    assert abs(n - 1001 * 0.05) < 6 * (1001 * 0.05 * 0.95) ** 0.5
