@@ -7,6 +7,8 @@
 // wave-uniform scalar load.  When the column count alone cannot fill the chip the batch is split
 // over gridDim.y and the partial sums are combined in split order by the finalize kernel, so the
 // result is reproducible (no float atomics).
+#include <stdlib.h>
+
 #include "dpk_common.h"
 #include "philox.h"
 
@@ -81,6 +83,11 @@ __device__ __forceinline__ f32x4 noise4(const float* __restrict__ noise, int64_t
     return z;
 }
 
+#ifndef DPK_K7_ROWS
+#define DPK_K7_ROWS 8
+#endif
+constexpr int K7_ROWS = DPK_K7_ROWS;  // independent 16-byte row loads in flight per thread
+
 // MODE 0: write partial sums (split-B); MODE 1: write summed only; MODE 2: summed (optional) + noise + scale
 template <int MODE>
 __global__ void __launch_bounds__(256) clip_reduce_kernel(const float* __restrict__ GS, int64_t gs_stride,
@@ -99,13 +106,14 @@ __global__ void __launch_bounds__(256) clip_reduce_kernel(const float* __restric
     const float* p = GS + (int64_t)b0 * gs_stride + j;
     f32x4 acc = {0.f, 0.f, 0.f, 0.f};
     int b = b0;
-    for (; b + 8 <= b1; b += 8) {
-        f32x4 v[8];
+    for (; b + K7_ROWS <= b1; b += K7_ROWS) {
+        f32x4 v[K7_ROWS];
 #pragma unroll
-        for (int u = 0; u < 8; ++u) v[u] = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(p + (int64_t)u * gs_stride));
+        for (int u = 0; u < K7_ROWS; ++u)
+            v[u] = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(p + (int64_t)u * gs_stride));
 #pragma unroll
-        for (int u = 0; u < 8; ++u) acc += v[u] * clip[b + u];
-        p += 8 * gs_stride;
+        for (int u = 0; u < K7_ROWS; ++u) acc += v[u] * clip[b + u];
+        p += K7_ROWS * gs_stride;
     }
     for (; b < b1; ++b) {
         const f32x4 v = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(p));
@@ -167,11 +175,20 @@ __global__ void __launch_bounds__(256) noise_scale_kernel(const float* __restric
 }
 
 inline int pick_nsplit(int B, int64_t P) {
+#ifdef DPK_LAB_ENV  // lab builds only: sweep the split factor without recompiling
+    if (const char* e = getenv("DPK_K7_NSPLIT")) {
+        int n = atoi(e);
+        if (n > B) n = B;
+        return n < 1 ? 1 : n;
+    }
+#endif
+    // Lab sweep (tools/lab/k7_sweep.py, MI355X): one long row stream per block is best once the grid has >= 2 blocks per
+    // CU; splitting the batch only pays for a mid-sized P (cfg2: 805 column blocks -> 3 splits, +2.5 %) and hurts a
+    // small batch (cfg1, B=64: 27 us unsplit vs 32 us in two halves).  Aim at ~2400 blocks, >= 128 rows per split.
     const int64_t blocks_x = (P / 4 + 255) / 256;
-    int64_t n = 4096 / (blocks_x > 0 ? blocks_x : 1);
-    if (n < 1) n = 1;
+    int64_t n = (2400 + blocks_x / 2) / (blocks_x > 0 ? blocks_x : 1);
     if (n > 32) n = 32;
-    const int by_batch = B / 32;  // keep >= 32 rows per split
+    const int by_batch = B / 128;
     if (n > by_batch) n = by_batch;
     if (n < 1) n = 1;
     return (int)n;
