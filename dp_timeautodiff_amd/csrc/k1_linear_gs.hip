@@ -31,30 +31,33 @@ constexpr int TK = 32;  // time steps staged per LDS chunk (even)
 #endif
 constexpr int STREAM_MAX_T = DPK_K1_STREAM_MAX_T;  // longest sequence kept whole in LDS (single-chunk streaming mode)
 
+typedef float f32x4u __attribute__((ext_vector_type(4), aligned(4)));  // global rows are only 4-byte aligned in general
+
 template <int W, int NTHR>
 __device__ __forceinline__ void stage_rows(float* __restrict__ s, const float* __restrict__ g, int t0, int rows,
-                                           int T, int c0, int dim, float scale, bool vec) {
-    // s[rows][W]  <-  scale * g[t0 + r][c0 + c]   (zero outside [0,T) x [0,dim))
-    if (vec) {
-        constexpr int W4 = W / 4;
-        for (int idx = threadIdx.x; idx < rows * W4; idx += NTHR) {
-            const int r = idx / W4;
-            const int c = (idx - r * W4) * 4;
-            const int t = t0 + r;
-            f32x4 v = {0.f, 0.f, 0.f, 0.f};
-            if (t < T && c0 + c < dim) v = *reinterpret_cast<const f32x4*>(g + (int64_t)t * dim + c0 + c);
-            v *= scale;
-            *reinterpret_cast<f32x4*>(s + r * W + c) = v;
+                                           int T, int c0, int dim, float scale) {
+    // s[rows][W]  <-  scale * g[t0 + r][c0 + c]   (zero outside [0,T) x [0,dim)).  One 16-byte global load per 4
+    // columns whatever the row alignment (gfx950 global loads need dword alignment only); the last, partial group
+    // of a row is read element by element so nothing past the row end is touched.
+    constexpr int W4 = W / 4;
+    for (int idx = threadIdx.x; idx < rows * W4; idx += NTHR) {
+        const int r = idx / W4;
+        const int c = (idx - r * W4) * 4;
+        const int t = t0 + r;
+        f32x4 v = {0.f, 0.f, 0.f, 0.f};
+        if (t < T) {
+            const float* src = g + (int64_t)t * dim + c0 + c;
+            const int left = dim - (c0 + c);
+            if (left >= 4) {
+                v = *reinterpret_cast<const f32x4u*>(src);
+            } else if (left > 0) {
+                v[0] = src[0];
+                if (left > 1) v[1] = src[1];
+                if (left > 2) v[2] = src[2];
+            }
         }
-    } else {
-        for (int idx = threadIdx.x; idx < rows * W; idx += NTHR) {
-            const int r = idx / W;
-            const int c = idx - r * W;
-            const int t = t0 + r;
-            float v = 0.f;
-            if (t < T && c0 + c < dim) v = g[(int64_t)t * dim + c0 + c];
-            s[r * W + c] = v * scale;
-        }
+        v *= scale;
+        *reinterpret_cast<f32x4*>(s + r * W + c) = v;
     }
 }
 
@@ -68,7 +71,7 @@ __global__ void __launch_bounds__(NW * 64) linear_gs_kernel(const float* __restr
                                                            float* __restrict__ normsq_part, int64_t part_stride,
                                                            int slot0, int B, int T, int in_f, int out_f,
                                                            int64_t gs_stride, int ld_w, float g_scale,
-                                                           int tiles_m, int tiles_n, int vecA, int vecG) {
+                                                           int tiles_m, int tiles_n) {
     constexpr int NTHR = NW * 64;
     constexpr int NCG = CS / (32 * NT);        // column groups per tile
     constexpr int UNITS = (RS / 32) * NCG;
@@ -133,8 +136,8 @@ __global__ void __launch_bounds__(NW * 64) linear_gs_kernel(const float* __restr
 
     if constexpr (STREAM) {
         const int rows2 = (T + 1) & ~1;  // MFMA consumes k in pairs; the pad row is zero-filled
-        stage_rows<RS, NTHR>(sG, Gb, 0, rows2, T, m0, out_f, g_scale, vecG != 0);
-        stage_rows<CS, NTHR>(sA, Ab, 0, rows2, T, n0, in_f, 1.0f, vecA != 0);
+        stage_rows<RS, NTHR>(sG, Gb, 0, rows2, T, m0, out_f, g_scale);
+        stage_rows<CS, NTHR>(sA, Ab, 0, rows2, T, n0, in_f, 1.0f);
         __syncthreads();
         for (int u = wave; u < UNITS; u += NW) {
             const int mr = u / NCG, cg = u - mr * NCG;
@@ -169,8 +172,8 @@ __global__ void __launch_bounds__(NW * 64) linear_gs_kernel(const float* __restr
             int rows = T - t0;
             if (rows > TK) rows = TK;
             const int rows2 = (rows + 1) & ~1;
-            stage_rows<RS, NTHR>(sG, Gb, t0, rows2, T, m0, out_f, g_scale, vecG != 0);
-            stage_rows<CS, NTHR>(sA, Ab, t0, rows2, T, n0, in_f, 1.0f, vecA != 0);
+            stage_rows<RS, NTHR>(sG, Gb, t0, rows2, T, m0, out_f, g_scale);
+            stage_rows<CS, NTHR>(sA, Ab, t0, rows2, T, n0, in_f, 1.0f);
             __syncthreads();
 #pragma unroll
             for (int k = 0; k < U; ++k) {
@@ -207,6 +210,183 @@ __global__ void __launch_bounds__(NW * 64) linear_gs_kernel(const float* __restr
     const float tot = block_sum<NW>(sq, red);
     if (threadIdx.x == 0) normsq_part[(int64_t)b * part_stride + slot0 + tile] = tot;
 }
+
+
+// ---- persistent, prefetching variant (T <= 48; lab: tools/lab/k1_lab.hip variant Q) --------------------------
+// At the sizes of the real step (arena of several GB, operands beyond the Infinity Cache) the launch-per-tile
+// kernel above loses 15-20 %: a workgroup's operand loads are issued after the previous occupant's stores and
+// queue behind them in the CU's in-order vector-memory pipe, so staging and storing alternate instead of
+// overlapping.  Here a fixed grid (2 workgroups per CU) walks the (sample, tile) items of its XCD; the operands of
+// item i+1 are fetched into registers BEFORE item i's MFMAs and stores are issued (the loads sit ahead of the
+// stores in the pipe and land under the MFMAs), and the two barriers per item wait for LDS only, never for the
+// wave's own stores.  The whole [T x RS] / [T x CS] slices stay resident (T <= 48: 74 KB), every wave computes a
+// unit and streams it out at once, as in STREAM mode.
+__device__ __forceinline__ void lds_only_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
+__device__ __forceinline__ f32x4 fetch4(const float* __restrict__ g, int t, int T, int col, int dim) {
+    f32x4 v = {0.f, 0.f, 0.f, 0.f};
+    if (t < T) {
+        const float* src = g + (int64_t)t * dim + col;
+        const int left = dim - col;
+        if (left >= 4) {
+            v = *reinterpret_cast<const f32x4u*>(src);
+        } else if (left > 0) {
+            v[0] = src[0];
+            if (left > 1) v[1] = src[1];
+            if (left > 2) v[2] = src[2];
+        }
+    }
+    return v;
+}
+
+// NG / NA: float4 registers per thread that hold the next item's G / A slice (>= ceil(Tp*RS/4/NTHR), same for CS).
+template <int NW, int RS, int CS, int NT, int NG, int NA, bool NTS>
+__global__ void __launch_bounds__(NW * 64) linear_gs_persist_kernel(
+    const float* __restrict__ A, const float* __restrict__ G, float* __restrict__ GSw, float* __restrict__ GSb,
+    float* __restrict__ normsq_part, int64_t part_stride, int slot0, int B, int T, int in_f, int out_f,
+    int64_t gs_stride, int ld_w, float g_scale, int tiles_m, int tiles_n) {
+    constexpr int NTHR = NW * 64;
+    constexpr int NCG = CS / (32 * NT);
+    constexpr int UNITS = (RS / 32) * NCG;
+    constexpr int R4 = RS / 4, C4 = CS / 4;
+    extern __shared__ __attribute__((aligned(16))) float smem[];  // [Tp][RS] G slice, [Tp][CS] A slice, red[2][NW]
+    const int Tp = (T + 1) & ~1;  // MFMA consumes k in pairs; the pad row is zero-filled
+    float* sG = smem;
+    float* sA = smem + Tp * RS;
+    float* red = sA + Tp * CS;
+    const int totG = Tp * R4, totA = Tp * C4;
+
+    // ---- XCD-aware item walk: this workgroup's XCD owns the samples b = xcd (mod 8) ----------------------
+    const int ntile = tiles_m * tiles_n;
+    const int xcd = blockIdx.x & 7;
+    const int nbx = gridDim.x >> 3;          // workgroups per XCD (grid is a multiple of 8)
+    const int nsx = (B - xcd + 7) / 8;       // samples on this XCD
+    const int64_t nitems = (int64_t)nsx * ntile;
+    int64_t item = blockIdx.x >> 3;
+    if (item >= nitems) return;              // uniform
+
+    const int lane = threadIdx.x & 63;
+    const int wave = threadIdx.x >> 6;
+    const int l31 = lane & 31;
+    const int lh = lane >> 5;
+
+    f32x4 rg[NG], ra[NA];
+    auto prefetch = [&](int64_t it) {
+        const int b = (int)(it / ntile) * 8 + xcd;
+        const int tile = (int)(it % ntile);
+        const int tm = tile / tiles_n, tn = tile - tm * tiles_n;
+        const float* Gb = G + (int64_t)b * T * out_f;
+        const float* Ab = A + (int64_t)b * T * in_f;
+#pragma unroll
+        for (int k = 0; k < NG; ++k) {
+            const int idx = threadIdx.x + k * NTHR;
+            const int t = idx / R4, c = (idx - t * R4) * 4;
+            rg[k] = fetch4(Gb, idx < totG ? t : T, T, tm * RS + c, out_f);
+        }
+#pragma unroll
+        for (int k = 0; k < NA; ++k) {
+            const int idx = threadIdx.x + k * NTHR;
+            const int t = idx / C4, c = (idx - t * C4) * 4;
+            ra[k] = fetch4(Ab, idx < totA ? t : T, T, tn * CS + c, in_f);
+        }
+    };
+
+    prefetch(item);
+    int parity = 0;
+    while (true) {
+#pragma unroll
+        for (int k = 0; k < NG; ++k) {
+            const int idx = threadIdx.x + k * NTHR;
+            if (idx < totG) *reinterpret_cast<f32x4*>(sG + idx * 4) = rg[k] * g_scale;
+        }
+#pragma unroll
+        for (int k = 0; k < NA; ++k) {
+            const int idx = threadIdx.x + k * NTHR;
+            if (idx < totA) *reinterpret_cast<f32x4*>(sA + idx * 4) = ra[k];
+        }
+        lds_only_barrier();
+        const int b = (int)(item / ntile) * 8 + xcd;
+        const int tile = (int)(item % ntile);
+        const int tm = tile / tiles_n, tn = tile - tm * tiles_n;
+        const int m0 = tm * RS, n0 = tn * CS;
+        const int64_t nitem = item + nbx;
+        const bool has_next = nitem < nitems;
+        if (has_next) prefetch(nitem);  // ahead of this item's stores in the vector-memory pipe
+
+        float sq = 0.f;
+        float* out = GSw + (int64_t)b * gs_stride;
+        for (int u = wave; u < UNITS; u += NW) {
+            const int mr = u / NCG, cg = u - mr * NCG;
+            const int wrow0 = m0 + mr * 32;
+            const int wcol0 = n0 + cg * (32 * NT);
+            if (wrow0 >= out_f || wcol0 >= in_f) continue;
+            f32x16 acc[NT];
+#pragma unroll
+            for (int j = 0; j < NT; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
+            const float* pg = sG + lh * RS + mr * 32 + l31;
+            const float* pa = sA + lh * CS + cg * (32 * NT) + l31;
+            for (int kk = 0; kk < Tp; kk += 2) {
+                const float a = pg[kk * RS];
+#pragma unroll
+                for (int j = 0; j < NT; ++j)
+                    acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, pa[kk * CS + j * 32], acc[j], 0, 0, 0);
+            }
+#pragma unroll
+            for (int j = 0; j < NT; ++j) {
+                const int col = wcol0 + j * 32 + l31;
+                if (col < ld_w) {  // columns in [in_f, ld_w) are row padding: written as exact zeros -> whole lines
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const int row = wrow0 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                        if (row < out_f) {
+                            const float v = acc[j][r];
+                            float* p = out + (int64_t)row * ld_w + col;
+                            if constexpr (NTS)
+                                __builtin_nontemporal_store(v, p);
+                            else
+                                *p = v;
+                            sq += v * v;
+                        }
+                    }
+                }
+            }
+        }
+        if (GSb != nullptr && tn == 0 && (int)threadIdx.x < RS && m0 + (int)threadIdx.x < out_f) {
+            float bias_acc = 0.f;
+            for (int r = 0; r < T; ++r) bias_acc += sG[r * RS + threadIdx.x];
+            GSb[(int64_t)b * gs_stride + m0 + threadIdx.x] = bias_acc;
+            sq += bias_acc * bias_acc;
+        }
+        sq = wave_sum(sq);
+        if (lane == 0) red[parity * NW + wave] = sq;
+        lds_only_barrier();  // every wave is done with this item's operands; red[parity] is complete
+        if (threadIdx.x == 0) {
+            float tot = 0.f;
+#pragma unroll
+            for (int i = 0; i < NW; ++i) tot += red[parity * NW + i];
+            normsq_part[(int64_t)b * part_stride + slot0 + tile] = tot;
+        }
+        parity ^= 1;
+        if (!has_next) break;
+        item = nitem;
+    }
+}
+
+inline int dpk_cu_count() {
+    static int cached[64] = {0};
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return 256;
+    if (cached[dev] == 0) {
+        int n = 0;
+        if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) n = 256;
+        cached[dev] = n;
+    }
+    return cached[dev];
+}
+
+constexpr int PERSIST_MAX_T = 48;
 
 struct Plan {
     int id;      // which instantiation
@@ -249,8 +429,6 @@ extern "C" int dpk_linear_grad_sample(const float* A, const float* G, float* GSw
     if (slot0 + ntile > part_stride) return DPK_ESLOTS;
     const int64_t nblk = ((int64_t)(B + 7) / 8) * 8 * ntile;
     if (nblk > 0x7fffffffLL) return DPK_ERANGE;
-    const int vecA = (in_f % 4 == 0) && dpk_aligned16(A);
-    const int vecG = (out_f % 4 == 0) && dpk_aligned16(G);
     // whole 128-byte lines per store segment: row stride and every row start multiples of 32 floats
     const int nt_store = (ld_w % 32 == 0) && (gs_stride % 32 == 0) && ((((uintptr_t)GSw) & 127u) == 0);
     hipStream_t s = (hipStream_t)stream;
@@ -265,7 +443,7 @@ extern "C" int dpk_linear_grad_sample(const float* A, const float* G, float* GSw
     }                                                                                                            \
     hipLaunchKernelGGL((linear_gs_kernel<NW, RS, CS, NT, ST, NTS>), grid, dim3(NW * 64), lds, s, A, G, GSw, GSb,  \
                        normsq_part, part_stride, slot0, B, T, in_f, out_f, gs_stride, ld_w, g_scale, tiles_m,    \
-                       tiles_n, vecA, vecG)
+                       tiles_n)
 #define DPK_K1_LAUNCH(NW, RS, CS, NT)                                                                          \
     do {                                                                                                       \
         const size_t lds = ((size_t)lds_rows * (RS + CS) + NW) * sizeof(float);                                \
@@ -274,6 +452,36 @@ extern "C" int dpk_linear_grad_sample(const float* A, const float* G, float* GSw
         else if (nt_store) { DPK_K1_GO(NW, RS, CS, NT, false, true); }                                         \
         else { DPK_K1_GO(NW, RS, CS, NT, false, false); }                                                      \
     } while (0)
+#ifndef DPK_K1_NO_PERSIST
+    if (p.id == 0 && T <= PERSIST_MAX_T) {
+        const int Tp = (T + 1) & ~1;
+        const size_t lds = ((size_t)Tp * (128 + 256) + 2 * 8) * sizeof(float);
+        int per_cu = (int)((160 * 1024) / (lds + 512));
+        if (per_cu > 2) per_cu = 2;
+        if (per_cu < 1) per_cu = 1;
+        int64_t want = (int64_t)dpk_cu_count() * per_cu;
+        if (want > nblk) want = nblk;
+        dim3 pgrid((unsigned)((want + 7) / 8 * 8));
+#define DPK_K1_PGO(NG, NA, NTS)                                                                                  \
+    do {                                                                                                         \
+        auto kfn = linear_gs_persist_kernel<8, 128, 256, 2, NG, NA, NTS>;                                        \
+        if (lds > 64 * 1024) {                                                                                   \
+            hipError_t e_ = hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize,    \
+                                                (int)lds);                                                       \
+            if (e_ != hipSuccess) return (int)e_;                                                                \
+        }                                                                                                        \
+        hipLaunchKernelGGL(kfn, pgrid, dim3(512), lds, s, A, G, GSw, GSb, normsq_part, part_stride, slot0, B, T, \
+                           in_f, out_f, gs_stride, ld_w, g_scale, tiles_m, tiles_n);                             \
+    } while (0)
+        if (T <= 32) {
+            if (nt_store) DPK_K1_PGO(2, 4, true); else DPK_K1_PGO(2, 4, false);
+        } else {
+            if (nt_store) DPK_K1_PGO(3, 6, true); else DPK_K1_PGO(3, 6, false);
+        }
+#undef DPK_K1_PGO
+        return dpk_launch_status();
+    }
+#endif
     switch (p.id) {
         case 0: DPK_K1_LAUNCH(8, 128, 256, 2); break;
         case 1: DPK_K1_LAUNCH(8, 128, 128, 2); break;

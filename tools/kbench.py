@@ -66,6 +66,8 @@ if __name__ == "__main__":
         bench_linear(512, 48, 256, 1024)
         bench_linear(512, 48, 512, 1024)
         bench_linear(512, 48, 500, 1000)
+        bench_linear(4096, 48, 250, 1000)
+        bench_linear(4096, 48, 500, 1000)
         bench_linear(128, 256, 2048, 2048)
         bench_linear(256, 256, 1024, 512)
     if which in ("all", "k7"):

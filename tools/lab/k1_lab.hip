@@ -461,6 +461,168 @@ __global__ void __launch_bounds__(NTHREADS) k1_res(const float* __restrict__ A, 
     if (threadIdx.x == 0) { float t = 0.f; for (int i = 0; i < NW; ++i) t += red[i]; part[(int64_t)b * 64 + (tile & 63)] = t; }
 }
 
+
+// Variant Q: persistent + operand-resident + register prefetch of the NEXT tile's operands issued before this
+// tile's MFMAs and stores (so they sit ahead of the stores in the CU's in-order vector-memory pipe), LDS-only
+// barriers (no vmcnt drain -> a wave never waits for its own stores at a barrier).
+__device__ __forceinline__ void lds_barrier_q() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
+template <int NW, int RS, int CS, int NT, int NG, int NA, int UNR = 1, int VAR = 0>
+__global__ void __launch_bounds__(NW * 64) k1_q(const float* __restrict__ A, const float* __restrict__ G,
+                                                float* __restrict__ GSw, int B, int T, int in_f, int out_f,
+                                                int64_t gs_stride, float g_scale, int tiles_m, int tiles_n,
+                                                float* __restrict__ part) {
+    constexpr int NTHR = NW * 64;
+    constexpr int NCG = CS / (32 * NT);
+    constexpr int UNITS = (RS / 32) * NCG;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int Tp = (T + 1) & ~1;
+    float* sG = smem;
+    float* sA = smem + (size_t)Tp * RS;
+    float* red = sA + (size_t)Tp * CS;  // [2][NW]
+    const int ntile = tiles_m * tiles_n;
+    const int xcd = blockIdx.x & 7;
+    const int lj = blockIdx.x >> 3;
+    const int nbx = gridDim.x >> 3;
+    const int nsx = (B - xcd + 7) / 8;  // samples on this XCD
+    const int64_t nitems = (int64_t)nsx * ntile;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int l31 = lane & 31, lh = lane >> 5;
+    constexpr int R4 = RS / 4, C4 = CS / 4;
+    const int totG = Tp * R4, totA = Tp * C4;
+
+    f32x4 rg[NG], ra[NA];
+    auto prefetch = [&](int64_t item) {
+        const int b = (int)(item / ntile) * 8 + xcd;
+        const int tile = (int)(item % ntile);
+        const int tm = tile / tiles_n, tn = tile - tm * tiles_n;
+        const int m0 = tm * RS, n0 = tn * CS;
+        const int bo = (VAR & 16) ? (b & 63) : b;
+        const float* Gb = G + (int64_t)bo * T * out_f;
+        const float* Ab = A + (int64_t)bo * T * in_f;
+#pragma unroll
+        for (int k = 0; k < NG; ++k) {
+            const int idx = threadIdx.x + k * NTHR;
+            const int t = idx / R4, c = (idx - t * R4) * 4;
+            f32x4 v = {0.f, 0.f, 0.f, 0.f};
+            if (!(VAR & 4) && idx < totG && t < T && m0 + c < out_f) v = *reinterpret_cast<const f32x4*>(Gb + (int64_t)t * out_f + m0 + c);
+            rg[k] = v;
+        }
+#pragma unroll
+        for (int k = 0; k < NA; ++k) {
+            const int idx = threadIdx.x + k * NTHR;
+            const int t = idx / C4, c = (idx - t * C4) * 4;
+            f32x4 v = {0.f, 0.f, 0.f, 0.f};
+            if (!(VAR & 4) && idx < totA && t < T && n0 + c < in_f) v = *reinterpret_cast<const f32x4*>(Ab + (int64_t)t * in_f + n0 + c);
+            ra[k] = v;
+        }
+    };
+
+    int64_t item = lj;
+    if (item >= nitems) return;
+    prefetch(item);
+    int parity = 0;
+    while (true) {
+#pragma unroll
+        for (int k = 0; k < NG; ++k) {
+            const int idx = threadIdx.x + k * NTHR;
+            if (!(VAR & 8) && idx < totG) *reinterpret_cast<f32x4*>(sG + idx * 4) = rg[k] * g_scale;
+        }
+#pragma unroll
+        for (int k = 0; k < NA; ++k) {
+            const int idx = threadIdx.x + k * NTHR;
+            if (!(VAR & 8) && idx < totA) *reinterpret_cast<f32x4*>(sA + idx * 4) = ra[k];
+        }
+        lds_barrier_q();
+        const int b = (int)(item / ntile) * 8 + xcd;
+        const int tile = (int)(item % ntile);
+        const int tm = tile / tiles_n, tn = tile - tm * tiles_n;
+        const int m0 = tm * RS, n0 = tn * CS;
+        const int64_t nitem = item + nbx;
+        const bool has_next = nitem < nitems;
+        if (has_next) prefetch(nitem);
+        float sq = 0.f;
+        float* out = GSw + (int64_t)b * gs_stride;
+        for (int u = wave; u < UNITS; u += NW) {
+            const int mr = u / NCG, cg = u - mr * NCG;
+            if (m0 + mr * 32 >= out_f || n0 + cg * (32 * NT) >= in_f) continue;
+            f32x16 acc[NT];
+#pragma unroll
+            for (int j = 0; j < NT; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
+            const float* pg = sG + lh * RS + mr * 32 + l31;
+            const float* pa = sA + lh * CS + cg * (32 * NT) + l31;
+            if constexpr (UNR > 1) {
+                // software-pipelined: the LDS reads of group g+1 are issued before the MFMAs of group g
+                constexpr int KU = UNR;
+                const int npairs = Tp >> 1;
+                const int ng = npairs / KU;
+                float ca[KU], cb[KU][NT], na[KU], nb[KU][NT];
+                if (ng > 0) {
+#pragma unroll
+                    for (int i = 0; i < KU; ++i) {
+                        ca[i] = pg[(2 * i) * RS];
+#pragma unroll
+                        for (int j = 0; j < NT; ++j) cb[i][j] = pa[(2 * i) * CS + j * 32];
+                    }
+                }
+                for (int g = 0; g < ng; ++g) {
+                    const int kn = (g + 1 < ng ? g + 1 : g) * KU * 2;
+#pragma unroll
+                    for (int i = 0; i < KU; ++i) {
+                        na[i] = pg[(kn + 2 * i) * RS];
+#pragma unroll
+                        for (int j = 0; j < NT; ++j) nb[i][j] = pa[(kn + 2 * i) * CS + j * 32];
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                    for (int i = 0; i < KU; ++i)
+#pragma unroll
+                        for (int j = 0; j < NT; ++j) acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(ca[i], cb[i][j], acc[j], 0, 0, 0);
+                    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                    for (int i = 0; i < KU; ++i) {
+                        ca[i] = na[i];
+#pragma unroll
+                        for (int j = 0; j < NT; ++j) cb[i][j] = nb[i][j];
+                    }
+                }
+                for (int kk = ng * KU * 2; kk < Tp; kk += 2) {
+                    const float a = pg[kk * RS];
+#pragma unroll
+                    for (int j = 0; j < NT; ++j) acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, pa[kk * CS + j * 32], acc[j], 0, 0, 0);
+                }
+            } else {
+                for (int kk = 0; kk < Tp; kk += 2) {
+                    const float a = pg[kk * RS];
+#pragma unroll
+                    for (int j = 0; j < NT; ++j) acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, pa[kk * CS + j * 32], acc[j], 0, 0, 0);
+                }
+            }
+            const int wrow0 = m0 + mr * 32;
+#pragma unroll
+            for (int j = 0; j < NT; ++j) {
+                const int col = n0 + (cg * NT + j) * 32 + l31;
+                if (col < in_f) {
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const int row = wrow0 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                        if (row < out_f) { const float v = acc[j][r]; if (!(VAR & 2)) __builtin_nontemporal_store(v, out + (int64_t)row * in_f + col); sq += v * v; }
+                    }
+                }
+            }
+        }
+        for (int off = 32; off >= 1; off >>= 1) sq += __shfl_xor(sq, off, 64);
+        if (lane == 0) red[parity * NW + wave] = sq;
+        lds_barrier_q();  // everyone is done reading this tile's operands; red[parity] complete
+        if (threadIdx.x == 0) { float t = 0.f; for (int i = 0; i < NW; ++i) t += red[parity * NW + i]; part[(int64_t)b * 64 + (tile & 63)] = t; }
+        parity ^= 1;
+        if (!has_next) break;
+        item = nitem;
+    }
+}
+
 struct Shape { int B, T, in_f, out_f; };
 
 template <typename F>
@@ -476,7 +638,7 @@ float time_it(F f, int iters = 50) {
 }
 
 int main(int argc, char** argv) {
-    std::vector<Shape> shapes = {{1024, 24, 512, 512}, {1024, 24, 256, 128}, {1024, 24, 416, 200}, {64, 24, 416, 200}, {512, 48, 512, 1000}, {512, 48, 256, 1000}, {1024, 24, 128, 32}, {1024, 24, 32, 128}};
+    std::vector<Shape> shapes = {{1024, 24, 512, 512}, {1024, 24, 256, 128}, {1024, 24, 416, 200}, {64, 24, 416, 200}, {512, 48, 512, 1000}, {512, 48, 256, 1000}, {1024, 24, 128, 32}, {1024, 24, 32, 128}, {4096, 24, 512, 512}, {2048, 48, 512, 1000}};
     int only = argc > 1 ? atoi(argv[1]) : -1;
     int si = -1;
     for (auto s : shapes) {
@@ -499,11 +661,11 @@ int main(int argc, char** argv) {
         auto report = [&](const char* name, float ms) { printf("  %-28s %8.1f us  %7.1f GB/s write\n", name, ms * 1e3, wbytes / ms / 1e6); };
 #define RUN(NAME, KERN) report(NAME, time_it([&] { hipLaunchKernelGGL((KERN), dim3((unsigned)nblk), dim3(256), 0, 0, A, G, GS, s.B, s.T, s.in_f, s.out_f, stride, 2.0f, tiles_m, tiles_n, part); }))
         auto run_product = [&]() {
-            typedef int (*fn_t)(const float*, const float*, float*, float*, float*, int64_t, int, int, int, int, int, int64_t, float, void*);
+            typedef int (*fn_t)(const float*, const float*, float*, float*, float*, int64_t, int, int, int, int, int, int64_t, int, float, void*);
             static fn_t fn = nullptr;
             if (!fn) { void* h = dlopen("dp_timeautodiff_amd/libdpk_gfx950.so", RTLD_NOW); if (!h) { printf("dlopen failed %s\n", dlerror()); exit(1);} fn = (fn_t)dlsym(h, "dpk_linear_grad_sample"); }
             float* part2; CK(hipMalloc(&part2, (size_t)s.B * 256 * 4));
-            report("PRODUCT dpk (no bias)", time_it([&] { int rc = fn(A, G, GS, nullptr, part2, 256, 0, s.B, s.T, s.in_f, s.out_f, stride, 2.0f, nullptr); if (rc) { printf("rc=%d\n", rc); exit(1);} }));
+            report("PRODUCT dpk (no bias)", time_it([&] { int rc = fn(A, G, GS, nullptr, part2, 256, 0, s.B, s.T, s.in_f, s.out_f, stride, s.in_f, 2.0f, nullptr); if (rc) { printf("rc=%d\n", rc); exit(1);} }));
             CK(hipFree(part2));
         };
         run_product();
@@ -558,6 +720,28 @@ int main(int argc, char** argv) {
             report(nm, time_it([&] { hipLaunchKernelGGL((k1_pipe<2, 2, 2>), dim3((unsigned)grid), dim3(256), 0, 0, A, G, GS, s.B, s.T, s.in_f, s.out_f, stride, 2.0f, tiles_m, tiles_n, part); }));
         }
         check("pipelined");
+
+        {
+            const int RSq = 128, CSq = 256;
+            const int Tp = (s.T + 1) & ~1;
+            const size_t lds = ((size_t)Tp * (RSq + CSq) + 32) * 4;
+            const int tm2 = (s.out_f + RSq - 1) / RSq, tn2 = (s.in_f + CSq - 1) / CSq;
+            if (s.T <= 48) {
+                CK(hipFuncSetAttribute((const void*)k1_q<8, 128, 256, 2, 3, 6>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 64));
+#define QRUN(NAME, BPC, ...) do { auto kq = k1_q<__VA_ARGS__>; CK(hipFuncSetAttribute((const void*)kq, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 64)); \
+                    CK(hipMemset(GS, 0, (size_t)s.B * stride * 4)); \
+                    report(NAME, time_it([&] { hipLaunchKernelGGL(kq, dim3(256 * BPC), dim3(512), lds, 0, A, G, GS, s.B, s.T, s.in_f, s.out_f, stride, 2.0f, tm2, tn2, part); })); } while (0)
+                QRUN("Q x2", 2, 8, 128, 256, 2, 3, 6, 1, 0);
+                QRUN("Q x2 pipe4", 2, 8, 128, 256, 2, 3, 6, 4, 0);
+                QRUN("Q x2 pipe2", 2, 8, 128, 256, 2, 3, 6, 2, 0);
+                QRUN("Q x2 pipe4 mfma-only", 2, 8, 128, 256, 2, 3, 6, 4, 14);
+                QRUN("Q x2 pipe4 no-store", 2, 8, 128, 256, 2, 3, 6, 4, 2);
+                QRUN("Q x2 pipe4 no-load", 2, 8, 128, 256, 2, 3, 6, 4, 12);
+                QRUN("Q x2 pipe4 L2-only loads", 2, 8, 128, 256, 2, 3, 6, 4, 16);
+                QRUN("Q x2 pipe4", 2, 8, 128, 256, 2, 3, 6, 4, 0);
+                check("Q");
+            }
+        }
         CK(hipFree(A)); CK(hipFree(G)); CK(hipFree(GS)); CK(hipFree(part)); CK(hipFree(ref));
     }
     return 0;
