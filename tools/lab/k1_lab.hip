@@ -731,14 +731,21 @@ int main(int argc, char** argv) {
 #define QRUN(NAME, BPC, ...) do { auto kq = k1_q<__VA_ARGS__>; CK(hipFuncSetAttribute((const void*)kq, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 64)); \
                     CK(hipMemset(GS, 0, (size_t)s.B * stride * 4)); \
                     report(NAME, time_it([&] { hipLaunchKernelGGL(kq, dim3(256 * BPC), dim3(512), lds, 0, A, G, GS, s.B, s.T, s.in_f, s.out_f, stride, 2.0f, tm2, tn2, part); })); } while (0)
-                QRUN("Q x2", 2, 8, 128, 256, 2, 3, 6, 1, 0);
-                QRUN("Q x2 pipe4", 2, 8, 128, 256, 2, 3, 6, 4, 0);
-                QRUN("Q x2 pipe2", 2, 8, 128, 256, 2, 3, 6, 2, 0);
-                QRUN("Q x2 pipe4 mfma-only", 2, 8, 128, 256, 2, 3, 6, 4, 14);
-                QRUN("Q x2 pipe4 no-store", 2, 8, 128, 256, 2, 3, 6, 4, 2);
-                QRUN("Q x2 pipe4 no-load", 2, 8, 128, 256, 2, 3, 6, 4, 12);
-                QRUN("Q x2 pipe4 L2-only loads", 2, 8, 128, 256, 2, 3, 6, 4, 16);
-                QRUN("Q x2 pipe4", 2, 8, 128, 256, 2, 3, 6, 4, 0);
+#define QRUN2(NAME, BPC, NW_, RS_, CS_, NT_, NG_, NA_) do { auto kq = k1_q<NW_, RS_, CS_, NT_, NG_, NA_, 1, 0>; \
+                    const size_t lds2 = ((size_t)Tp * (RS_ + CS_) + 64) * 4; \
+                    if (lds2 * BPC > 160 * 1024) break; \
+                    const int tma = (s.out_f + RS_ - 1) / RS_, tna = (s.in_f + CS_ - 1) / CS_; \
+                    CK(hipFuncSetAttribute((const void*)kq, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 64)); \
+                    CK(hipMemset(GS, 0, (size_t)s.B * stride * 4)); \
+                    report(NAME, time_it([&] { hipLaunchKernelGGL(kq, dim3(256 * BPC), dim3(NW_ * 64), lds2, 0, A, G, GS, s.B, s.T, s.in_f, s.out_f, stride, 2.0f, tma, tna, part); })); } while (0)
+                QRUN2("Q 128x256 8w x2", 2, 8, 128, 256, 2, 3, 6);
+                QRUN2("Q 256x256 16w x1", 1, 16, 256, 256, 2, 3, 3);
+                QRUN2("Q 256x256 8w x1", 1, 8, 256, 256, 2, 6, 6);
+                QRUN2("Q 256x256 8w x2", 2, 8, 256, 256, 2, 6, 6);
+                QRUN2("Q 128x512 8w x2", 2, 8, 128, 512, 2, 3, 12);
+                QRUN2("Q 128x512 16w x1", 1, 16, 128, 512, 2, 2, 6);
+                QRUN2("Q 128x256 16w x1", 1, 16, 128, 256, 2, 2, 3);
+                QRUN2("Q 128x256 8w x2", 2, 8, 128, 256, 2, 3, 6);
                 check("Q");
             }
         }
