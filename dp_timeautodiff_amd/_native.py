@@ -27,6 +27,8 @@ EXPORTS = {
     "dpk_normsq_slots": (c_int, [c_int64]),
     "dpk_linear_grad_sample": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int,
                                        c_int, c_int, c_int, c_int, c_int64, c_int, c_float, c_void_p]),
+    "dpk_linear_grad_sample_group": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_int64,
+                                             c_int, c_int, c_int, c_int, c_int64, c_int, c_float, c_void_p]),
     "dpk_embedding_grad_sample": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int,
                                           c_int, c_int, c_int, c_int, c_int64, c_float, c_void_p]),
     "dpk_layernorm_grad_sample": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int,
@@ -156,6 +158,46 @@ def linear_grad_sample(A, G, gs_w: FlatView, gs_b: Optional[FlatView], part: tor
                                        _ptr(part), part.stride(0), slot0, B, T, in_f, out_f, gs_w.stride, ld_w,
                                        float(g_scale), _stream())
     _check(rc, "dpk_linear_grad_sample")
+
+
+K1_MAX_JOBS = 8
+
+
+def linear_grad_sample_group(jobs, part: torch.Tensor, g_scale: float, ld_w: Optional[int] = None):
+    """jobs: list of (A, G, gs_w, gs_b or None, slot0) of ONE shape; one launch (dpk_linear_grad_sample_group)."""
+    if not 1 <= len(jobs) <= K1_MAX_JOBS:
+        raise DpkError(f"1..{K1_MAX_JOBS} jobs per group, got {len(jobs)}")
+    A0, G0, w0, _, _ = jobs[0]
+    _req(part, "normsq_part")
+    if A0.dim() != 3 or G0.dim() != 3:
+        raise DpkError("A and G must be contiguous [B,T,features]")
+    B, T, in_f = A0.shape
+    out_f = G0.shape[2]
+    ld_w = in_f if ld_w is None else int(ld_w)
+    if part.shape[0] < B or part.dim() != 2 or part.stride(1) != 1:
+        raise DpkError("partial buffer has fewer rows than the batch")
+    for A, G, gs_w, gs_b, slot0 in jobs:
+        _req(A, "A"); _req(G, "G"); _req(gs_w.base, "arena")
+        if tuple(A.shape) != (B, T, in_f) or tuple(G.shape) != (B, T, out_f) or not A.is_contiguous() \
+                or not G.is_contiguous():
+            raise DpkError("all jobs of a group must share one contiguous [B,T,in] / [B,T,out] shape")
+        if ld_w < in_f or gs_w.numel != ld_w * out_f or (gs_b is not None and gs_b.numel != out_f):
+            raise DpkError("grad-sample window does not match the layer shape")
+        if gs_w.base.shape[0] < B or gs_w.stride != w0.stride:
+            raise DpkError("arena has fewer rows than the batch / jobs live in different arenas")
+        if gs_b is not None and gs_b.base.data_ptr() != gs_w.base.data_ptr():
+            raise DpkError("weight and bias windows must live in the same arena")
+    if B == 0:
+        return
+    n = len(jobs)
+    arr = lambda vals: (c_void_p * n)(*vals)
+    pa = arr([j[0].data_ptr() for j in jobs]); pg = arr([j[1].data_ptr() for j in jobs])
+    pw = arr([j[2].ptr.value for j in jobs])
+    pb = arr([None if j[3] is None else j[3].ptr.value for j in jobs])
+    slots = (c_int * n)(*[int(j[4]) for j in jobs])
+    rc = load().dpk_linear_grad_sample_group(pa, pg, pw, pb, slots, n, _ptr(part), part.stride(0), B, T, in_f, out_f,
+                                             w0.stride, ld_w, float(g_scale), _stream())
+    _check(rc, "dpk_linear_grad_sample_group")
 
 
 def embedding_grad_sample(idx, G, gs: FlatView, V: int, part: torch.Tensor, slot0: int, g_scale: float):

@@ -239,11 +239,20 @@ __device__ __forceinline__ f32x4 fetch4(const float* __restrict__ g, int t, int 
     return v;
 }
 
+// Up to DPK_K1_MAX_JOBS same-shape layers (the six gate Linears of a GRU pair) share one launch: by-value table.
+struct K1Jobs {
+    const float* A[DPK_K1_MAX_JOBS];
+    const float* G[DPK_K1_MAX_JOBS];
+    float* W[DPK_K1_MAX_JOBS];
+    float* Bi[DPK_K1_MAX_JOBS];  // nullable
+    int slot0[DPK_K1_MAX_JOBS];
+    int n;
+};
+
 // NG / NA: float4 registers per thread that hold the next item's G / A slice (>= ceil(Tp*RS/4/NTHR), same for CS).
 template <int NW, int RS, int CS, int NT, int NG, int NA, bool NTS>
 __global__ void __launch_bounds__(NW * 64) linear_gs_persist_kernel(
-    const float* __restrict__ A, const float* __restrict__ G, float* __restrict__ GSw, float* __restrict__ GSb,
-    float* __restrict__ normsq_part, int64_t part_stride, int slot0, int B, int T, int in_f, int out_f,
+    const K1Jobs jobs, float* __restrict__ normsq_part, int64_t part_stride, int B, int T, int in_f, int out_f,
     int64_t gs_stride, int ld_w, float g_scale, int tiles_m, int tiles_n) {
     constexpr int NTHR = NW * 64;
     constexpr int NCG = CS / (32 * NT);
@@ -261,7 +270,8 @@ __global__ void __launch_bounds__(NW * 64) linear_gs_persist_kernel(
     const int xcd = blockIdx.x & 7;
     const int nbx = gridDim.x >> 3;          // workgroups per XCD (grid is a multiple of 8)
     const int nsx = (B - xcd + 7) / 8;       // samples on this XCD
-    const int64_t nitems = (int64_t)nsx * ntile;
+    const int64_t per_job = (int64_t)nsx * ntile;
+    const int64_t nitems = per_job * jobs.n;  // job-major: (job, sample, tile)
     int64_t item = blockIdx.x >> 3;
     if (item >= nitems) return;              // uniform
 
@@ -272,11 +282,13 @@ __global__ void __launch_bounds__(NW * 64) linear_gs_persist_kernel(
 
     f32x4 rg[NG], ra[NA];
     auto prefetch = [&](int64_t it) {
-        const int b = (int)(it / ntile) * 8 + xcd;
-        const int tile = (int)(it % ntile);
+        const int job = (int)(it / per_job);
+        const int64_t rem = it - job * per_job;
+        const int b = (int)(rem / ntile) * 8 + xcd;
+        const int tile = (int)(rem % ntile);
         const int tm = tile / tiles_n, tn = tile - tm * tiles_n;
-        const float* Gb = G + (int64_t)b * T * out_f;
-        const float* Ab = A + (int64_t)b * T * in_f;
+        const float* Gb = jobs.G[job] + (int64_t)b * T * out_f;
+        const float* Ab = jobs.A[job] + (int64_t)b * T * in_f;
 #pragma unroll
         for (int k = 0; k < NG; ++k) {
             const int idx = threadIdx.x + k * NTHR;
@@ -305,10 +317,15 @@ __global__ void __launch_bounds__(NW * 64) linear_gs_persist_kernel(
             if (idx < totA) *reinterpret_cast<f32x4*>(sA + idx * 4) = ra[k];
         }
         lds_only_barrier();
-        const int b = (int)(item / ntile) * 8 + xcd;
-        const int tile = (int)(item % ntile);
+        const int job = (int)(item / per_job);
+        const int64_t rem = item - job * per_job;
+        const int b = (int)(rem / ntile) * 8 + xcd;
+        const int tile = (int)(rem % ntile);
         const int tm = tile / tiles_n, tn = tile - tm * tiles_n;
         const int m0 = tm * RS, n0 = tn * CS;
+        float* __restrict__ GSw = jobs.W[job];
+        float* __restrict__ GSb = jobs.Bi[job];
+        const int slot0 = jobs.slot0[job];
         const int64_t nitem = item + nbx;
         const bool has_next = nitem < nitems;
         if (has_next) prefetch(nitem);  // ahead of this item's stores in the vector-memory pipe
@@ -415,52 +432,45 @@ extern "C" int dpk_linear_slots(int in_features, int out_features) {
     return tiles_m * tiles_n;
 }
 
-extern "C" int dpk_linear_grad_sample(const float* A, const float* G, float* GSw, float* GSb, float* normsq_part,
-                                      int64_t part_stride, int slot0, int B, int T, int in_f, int out_f,
-                                      int64_t gs_stride, int ld_w, float g_scale, void* stream) {
-    if (!A || !G || !GSw || !normsq_part) return DPK_EINVAL;
-    if (B < 0 || T <= 0 || in_f <= 0 || out_f <= 0 || slot0 < 0) return DPK_EINVAL;
+namespace {
+
+int k1_launch(const float* const* A, const float* const* G, float* const* GSw, float* const* GSb, const int* slot0,
+              int n_jobs, float* normsq_part, int64_t part_stride, int B, int T, int in_f, int out_f,
+              int64_t gs_stride, int ld_w, float g_scale, void* stream) {
+    if (!A || !G || !GSw || !slot0 || !normsq_part || n_jobs < 1 || n_jobs > DPK_K1_MAX_JOBS) return DPK_EINVAL;
+    if (B < 0 || T <= 0 || in_f <= 0 || out_f <= 0) return DPK_EINVAL;
     if (ld_w < in_f || gs_stride < (int64_t)ld_w * out_f) return DPK_EINVAL;
-    if (B == 0) return DPK_OK;
     const Plan p = pick_plan(in_f, out_f);
     const int tiles_m = (out_f + p.rs - 1) / p.rs;
     const int tiles_n = (in_f + p.cs - 1) / p.cs;
     const int64_t ntile = (int64_t)tiles_m * tiles_n;
-    if (slot0 + ntile > part_stride) return DPK_ESLOTS;
+    int nt_store = (ld_w % 32 == 0) && (gs_stride % 32 == 0);
+    for (int j = 0; j < n_jobs; ++j) {
+        if (!A[j] || !G[j] || !GSw[j] || slot0[j] < 0) return DPK_EINVAL;
+        if (slot0[j] + ntile > part_stride) return DPK_ESLOTS;
+        // whole 128-byte lines per store segment: row stride and every row start multiples of 32 floats
+        nt_store = nt_store && ((((uintptr_t)GSw[j]) & 127u) == 0);
+    }
+    if (B == 0) return DPK_OK;
     const int64_t nblk = ((int64_t)(B + 7) / 8) * 8 * ntile;
-    if (nblk > 0x7fffffffLL) return DPK_ERANGE;
-    // whole 128-byte lines per store segment: row stride and every row start multiples of 32 floats
-    const int nt_store = (ld_w % 32 == 0) && (gs_stride % 32 == 0) && ((((uintptr_t)GSw) & 127u) == 0);
+    if (nblk * n_jobs > 0x7fffffffLL) return DPK_ERANGE;
     hipStream_t s = (hipStream_t)stream;
-    dim3 grid((unsigned)nblk);
-    const bool stream_mode = T <= STREAM_MAX_T;
-    const int lds_rows = stream_mode ? ((T + 1) & ~1) : TK;
-#define DPK_K1_GO(NW, RS, CS, NT, ST, NTS)                                                                       \
-    if (lds > 64 * 1024) {                                                                                       \
-        hipError_t e_ = hipFuncSetAttribute((const void*)linear_gs_kernel<NW, RS, CS, NT, ST, NTS>,              \
-                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);               \
-        if (e_ != hipSuccess) return (int)e_;                                                                    \
-    }                                                                                                            \
-    hipLaunchKernelGGL((linear_gs_kernel<NW, RS, CS, NT, ST, NTS>), grid, dim3(NW * 64), lds, s, A, G, GSw, GSb,  \
-                       normsq_part, part_stride, slot0, B, T, in_f, out_f, gs_stride, ld_w, g_scale, tiles_m,    \
-                       tiles_n)
-#define DPK_K1_LAUNCH(NW, RS, CS, NT)                                                                          \
-    do {                                                                                                       \
-        const size_t lds = ((size_t)lds_rows * (RS + CS) + NW) * sizeof(float);                                \
-        if (stream_mode && nt_store) { DPK_K1_GO(NW, RS, CS, NT, true, true); }                                \
-        else if (stream_mode) { DPK_K1_GO(NW, RS, CS, NT, true, false); }                                      \
-        else if (nt_store) { DPK_K1_GO(NW, RS, CS, NT, false, true); }                                         \
-        else { DPK_K1_GO(NW, RS, CS, NT, false, false); }                                                      \
-    } while (0)
 #ifndef DPK_K1_NO_PERSIST
     if (p.id == 0 && T <= PERSIST_MAX_T) {
+        K1Jobs jobs;
+        for (int j = 0; j < DPK_K1_MAX_JOBS; ++j) {
+            const int q = j < n_jobs ? j : 0;
+            jobs.A[j] = A[q]; jobs.G[j] = G[q]; jobs.W[j] = GSw[q]; jobs.Bi[j] = GSb ? GSb[q] : nullptr;
+            jobs.slot0[j] = slot0[q];
+        }
+        jobs.n = n_jobs;
         const int Tp = (T + 1) & ~1;
         const size_t lds = ((size_t)Tp * (128 + 256) + 2 * 8) * sizeof(float);
         int per_cu = (int)((160 * 1024) / (lds + 512));
         if (per_cu > 2) per_cu = 2;
         if (per_cu < 1) per_cu = 1;
         int64_t want = (int64_t)dpk_cu_count() * per_cu;
-        if (want > nblk) want = nblk;
+        if (want > nblk * n_jobs) want = nblk * n_jobs;
         dim3 pgrid((unsigned)((want + 7) / 8 * 8));
 #define DPK_K1_PGO(NG, NA, NTS)                                                                                  \
     do {                                                                                                         \
@@ -470,8 +480,8 @@ extern "C" int dpk_linear_grad_sample(const float* A, const float* G, float* GSw
                                                 (int)lds);                                                       \
             if (e_ != hipSuccess) return (int)e_;                                                                \
         }                                                                                                        \
-        hipLaunchKernelGGL(kfn, pgrid, dim3(512), lds, s, A, G, GSw, GSb, normsq_part, part_stride, slot0, B, T, \
-                           in_f, out_f, gs_stride, ld_w, g_scale, tiles_m, tiles_n);                             \
+        hipLaunchKernelGGL(kfn, pgrid, dim3(512), lds, s, jobs, normsq_part, part_stride, B, T, in_f, out_f,     \
+                           gs_stride, ld_w, g_scale, tiles_m, tiles_n);                                          \
     } while (0)
         if (T <= 32) {
             if (nt_store) DPK_K1_PGO(2, 4, true); else DPK_K1_PGO(2, 4, false);
@@ -482,6 +492,27 @@ extern "C" int dpk_linear_grad_sample(const float* A, const float* G, float* GSw
         return dpk_launch_status();
     }
 #endif
+    dim3 grid((unsigned)nblk);
+    const bool stream_mode = T <= STREAM_MAX_T;
+    const int lds_rows = stream_mode ? ((T + 1) & ~1) : TK;
+#define DPK_K1_GO(NW, RS, CS, NT, ST, NTS)                                                                       \
+    if (lds > 64 * 1024) {                                                                                       \
+        hipError_t e_ = hipFuncSetAttribute((const void*)linear_gs_kernel<NW, RS, CS, NT, ST, NTS>,              \
+                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);               \
+        if (e_ != hipSuccess) return (int)e_;                                                                    \
+    }                                                                                                            \
+    for (int j = 0; j < n_jobs; ++j)                                                                             \
+        hipLaunchKernelGGL((linear_gs_kernel<NW, RS, CS, NT, ST, NTS>), grid, dim3(NW * 64), lds, s, A[j], G[j], \
+                           GSw[j], GSb ? GSb[j] : nullptr, normsq_part, part_stride, slot0[j], B, T, in_f,      \
+                           out_f, gs_stride, ld_w, g_scale, tiles_m, tiles_n)
+#define DPK_K1_LAUNCH(NW, RS, CS, NT)                                                                          \
+    do {                                                                                                       \
+        const size_t lds = ((size_t)lds_rows * (RS + CS) + NW) * sizeof(float);                                \
+        if (stream_mode && nt_store) { DPK_K1_GO(NW, RS, CS, NT, true, true); }                                \
+        else if (stream_mode) { DPK_K1_GO(NW, RS, CS, NT, true, false); }                                      \
+        else if (nt_store) { DPK_K1_GO(NW, RS, CS, NT, false, true); }                                         \
+        else { DPK_K1_GO(NW, RS, CS, NT, false, false); }                                                      \
+    } while (0)
     switch (p.id) {
         case 0: DPK_K1_LAUNCH(8, 128, 256, 2); break;
         case 1: DPK_K1_LAUNCH(8, 128, 128, 2); break;
@@ -492,4 +523,21 @@ extern "C" int dpk_linear_grad_sample(const float* A, const float* G, float* GSw
 #undef DPK_K1_LAUNCH
 #undef DPK_K1_GO
     return dpk_launch_status();
+}
+
+}  // namespace
+
+extern "C" int dpk_linear_grad_sample(const float* A, const float* G, float* GSw, float* GSb, float* normsq_part,
+                                      int64_t part_stride, int slot0, int B, int T, int in_f, int out_f,
+                                      int64_t gs_stride, int ld_w, float g_scale, void* stream) {
+    return k1_launch(&A, &G, &GSw, GSb ? &GSb : nullptr, &slot0, 1, normsq_part, part_stride, B, T, in_f, out_f,
+                     gs_stride, ld_w, g_scale, stream);
+}
+
+extern "C" int dpk_linear_grad_sample_group(const float* const* A, const float* const* G, float* const* GSw,
+                                            float* const* GSb, const int* slot0, int n_jobs, float* normsq_part,
+                                            int64_t part_stride, int B, int T, int in_f, int out_f,
+                                            int64_t gs_stride, int ld_w, float g_scale, void* stream) {
+    return k1_launch(A, G, GSw, GSb, slot0, n_jobs, normsq_part, part_stride, B, T, in_f, out_f, gs_stride, ld_w,
+                     g_scale, stream);
 }

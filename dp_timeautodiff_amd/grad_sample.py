@@ -265,6 +265,7 @@ class GradSampleModule(nn.Module):
             self._handles.append(sub.register_full_backward_hook(self._make_bwd(layer)))
         # fused recurrences hand their gates' stacked (activations, backprops) over directly (no per-call hooks)
         self._by_module = {id(l.module): l for l in self._layers}
+        self._deferred = None  # list while _fused_sink_many collects launches
         for sub in m.modules():
             if isinstance(sub, FusedLinearCellGRU) or "_dpk_sink" in sub.__dict__:  # fused GRU modules, DPLSTM cells
                 object.__setattr__(sub, "_dpk_sink", self._fused_sink)
@@ -445,6 +446,35 @@ class GradSampleModule(nn.Module):
     def _fused_sink(self, module: nn.Module, A: torch.Tensor, G: torch.Tensor):
         self._emit(self._by_module[id(module)], A, G)
 
+    def _fused_sink_many(self, jobs):
+        """jobs: [(module, A, G)] produced together (the gate Linears of the GRUs of one K8 launch).  Same
+        bookkeeping as one _fused_sink call each; Linear jobs of one shape share a grouped K1 launch."""
+        self._deferred = []
+        try:
+            for module, A, G in jobs:
+                self._emit(self._by_module[id(module)], A, G)
+            pending, self._deferred = self._deferred, None
+            groups = {}
+            for job in pending:
+                layer, m, A, G, arena, row0, part, g_scale = job
+                ld = arena.window(m.weight).ld if layer.kind == "linear" else None
+                key = (layer.kind, tuple(A.shape), tuple(G.shape), row0, ld, g_scale) if layer.kind == "linear" else id(job)
+                groups.setdefault(key, []).append(job)
+            for key, members in groups.items():
+                if len(members) == 1 or members[0][0].kind != "linear":
+                    for job in members:
+                        self._launch(*job)
+                    continue
+                for i in range(0, len(members), _native.K1_MAX_JOBS):
+                    chunk = members[i:i + _native.K1_MAX_JOBS]
+                    _, _, _, _, arena, row0, part, g_scale = chunk[0]
+                    _native.linear_grad_sample_group(
+                        [(A, G, arena.flat(m.weight, row0), arena.flat(m.bias, row0) if m.bias is not None else None,
+                          layer.slot0) for layer, m, A, G, _, _, _, _ in chunk],
+                        part, g_scale, ld_w=key[4])
+        finally:
+            self._deferred = None
+
     def _emit(self, layer: _Layer, A: torch.Tensor, G: torch.Tensor):
         """Contract one layer's stacked activations A and backprops G into its arena window."""
         arena = self.arena
@@ -477,6 +507,8 @@ class GradSampleModule(nn.Module):
             self._side.wait_stream(torch.cuda.current_stream(arena.device))
             with torch.cuda.stream(self._side):
                 self._launch(layer, m, A, G, arena, row0, part, g_scale)
+        elif B > 0 and self._deferred is not None:
+            self._deferred.append((layer, m, A, G, arena, row0, part, g_scale))
         elif B > 0:
             self._launch(layer, m, A, G, arena, row0, part, g_scale)
         self._publish(m, arena, row0, B, k)

@@ -59,13 +59,23 @@ class _Recurrence(torch.autograd.Function):
         douts = [None if d is None else d.contiguous() for d in douts]
         dxp, Gz, Gr, Gn, dh0 = _native.gru_backward(douts, None, Z, R, N, Azr, *packs, want_dh0)
         grads = []
+        if ctx.feed:  # per-sample gradients: K1 straight from the kernels' buffers
+            jobs, hosts = [], set()
+            for g in range(G):
+                owner = owners[g]
+                if owner._dpk_sink is not None:
+                    hosts.add(id(getattr(owner._dpk_sink, "__self__", owner._dpk_sink)))
+                    jobs.append((owner._dpk_sink, owner.update_gate, Azr[g], Gz[g]))
+                    jobs.append((owner._dpk_sink, owner.reset_gate, Azr[g], Gr[g]))
+                    jobs.append((owner._dpk_sink, owner.new_gate, An[g], Gn[g]))
+            many = getattr(getattr(jobs[0][0], "__self__", None), "_fused_sink_many", None) if jobs else None
+            if many is not None and len(hosts) == 1:
+                many([j[1:] for j in jobs])  # same-shape gates of all G GRUs share one grouped K1 launch
+            else:
+                for sink, mod, a, gg in jobs:
+                    sink(mod, a, gg)
         for g in range(G):
             owner = owners[g]
-            sink = owner._dpk_sink
-            if ctx.feed and sink is not None:  # per-sample gradients: K1 straight from the kernels' buffers
-                sink(owner.update_gate, Azr[g], Gz[g])
-                sink(owner.reset_gate, Azr[g], Gr[g])
-                sink(owner.new_gate, An[g], Gn[g])
             gw = [None] * 6
             for k, (a, gg) in enumerate(((Azr[g], Gz[g]), (Azr[g], Gr[g]), (An[g], Gn[g]))):
                 if need[8 * g + 2 + 2 * k]:

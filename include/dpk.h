@@ -67,6 +67,20 @@ int dpk_linear_grad_sample(const float* A, const float* G, float* GSw, float* GS
                            int64_t gs_stride, int ld_w, float g_scale, void* stream);
 
 /*
+ * K1, grouped: n_jobs <= DPK_K1_MAX_JOBS layers of the SAME shape (B, T, in, out, ld_w) in one launch — the update /
+ * reset / new gate Linears of CustomGRU (timeautoencoder.py:63-67) for encoder_mu and encoder_logvar (:117-120) reach
+ * the sampler back to back, and six thin launches leave six tails.  A, G, GSw, GSb (nullable as a whole or per entry)
+ * and slot0 are HOST arrays of n_jobs entries (device pointers / slot indices); every job writes its own
+ * dpk_linear_slots(in,out) partials at slot0[j].  Results are identical to n_jobs dpk_linear_grad_sample calls.
+ */
+#define DPK_K1_MAX_JOBS 8
+int dpk_linear_grad_sample_group(const float* const* A, const float* const* G, float* const* GSw,
+                                 float* const* GSb, const int* slot0, int n_jobs,
+                                 float* normsq_part, int64_t part_stride,
+                                 int B, int T, int in_features, int out_features,
+                                 int64_t gs_stride, int ld_w, float g_scale, void* stream);
+
+/*
  * K3 — per-sample gradient of nn.Embedding.  Replaces Opacus' Embedding sampler
  *     zeros(B,V,E).scatter_add_(1, index, backprops)     (Embedding_data, timeautoencoder.py:128-133,160-164)
  * idx [B,T] int64 (values in [0,V)), G [B,T,E]; GS[b,v,:] = sum_{t: idx[b,t]=v} g_scale*G[b,t,:], summed in

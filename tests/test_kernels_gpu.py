@@ -106,6 +106,62 @@ def test_linear_grad_sample_is_deterministic(nat):
         assert torch.equal(o[0], outs[0][0]) and torch.equal(o[1], outs[0][1])
 
 
+@pytest.mark.parametrize("B,T,in_f,out_f", [(150, 24, 400, 200), (100, 48, 300, 260), (41, 31, 250, 1000)])
+def test_linear_grad_sample_persistent_multi_item(nat, B, T, in_f, out_f):
+    """More (sample, tile) items than the persistent grid has workgroups: every workgroup walks several items
+    (register prefetch of the next item, LDS-only barriers, partial-slot double buffer)."""
+    from oracle import opacus_ref as O
+    g = torch.Generator().manual_seed(B + T)
+    A = torch.randn(B, T, in_f, generator=g)
+    G = torch.randn(B, T, out_f, generator=g) * 0.01
+    gw_ref, gb_ref = O.linear_grad_sample(A, G * float(B), True)
+    ld = (in_f + 31) // 32 * 32
+    nw = ld * out_f
+    base = torch.full((B, 64 + nw + out_f + 64), 3.0, device="cuda")
+    slots = nat.linear_slots(in_f, out_f)
+    part = torch.zeros(B, slots, device="cuda")
+    nat.linear_grad_sample(A.cuda(), G.cuda(), nat.FlatView(base, 64, nw), nat.FlatView(base, 64 + nw, out_f), part, 0,
+                           float(B), ld_w=ld)
+    out = base.cpu()
+    w = out[:, 64:64 + nw].reshape(B, out_f, ld)
+    assert rel_err(w[:, :, :in_f].numpy(), gw_ref.numpy()) < TOL
+    assert (w[:, :, in_f:] == 0).all()
+    assert rel_err(out[:, 64 + nw:64 + nw + out_f].numpy(), gb_ref.numpy()) < TOL
+    assert (out[:, :64] == 3).all() and (out[:, 64 + nw + out_f:] == 3).all()
+    ref_sq = (gw_ref.double() ** 2).sum((1, 2)) + (gb_ref.double() ** 2).sum(1)
+    assert rel_err(part.cpu().double().sum(1).numpy(), ref_sq.numpy()) < TOL
+
+
+@pytest.mark.parametrize("B,T,in_f,out_f,n", [(64, 24, 256, 128, 6), (9, 24, 400, 200, 3), (5, 24, 32, 128, 4),
+                                               (3, 70, 300, 140, 2), (130, 48, 256, 250, 8)])
+def test_linear_grad_sample_group_equals_single_launches(nat, B, T, in_f, out_f, n):
+    """dpk_linear_grad_sample_group == n dpk_linear_grad_sample calls, bit for bit (also on the plans and sequence
+    lengths where the library falls back to one launch per job)."""
+    g = torch.Generator().manual_seed(n)
+    nw = in_f * out_f
+    width = n * (nw + out_f + 64)
+    slots = nat.linear_slots(in_f, out_f)
+    As = [torch.randn(B, T, in_f, generator=g).cuda() for _ in range(n)]
+    Gs = [torch.randn(B, T, out_f, generator=g).cuda() for _ in range(n)]
+    outs = []
+    for grouped in (False, True):
+        base, off = _arena(B, width)
+        part = torch.full((B, n * slots + 1), -1.0, device="cuda")
+        jobs = []
+        for j in range(n):
+            o = off + j * (nw + out_f + 64)
+            vb = nat.FlatView(base, o + nw, out_f) if j % 2 == 0 else None  # mixed bias / no bias
+            jobs.append((As[j], Gs[j], nat.FlatView(base, o, nw), vb, 1 + j * slots))
+        if grouped:
+            nat.linear_grad_sample_group(jobs, part, float(B))
+        else:
+            for A, G, vw, vb, s0 in jobs:
+                nat.linear_grad_sample(A, G, vw, vb, part, s0, float(B))
+        outs.append((base.cpu(), part.cpu()))
+    assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
+    assert (outs[1][1][:, 0] == -1).all() and (outs[1][1][:, 1:] >= 0).all()
+
+
 @pytest.mark.parametrize("case", ["vae_small_mixed.npz", "vae_small_nums.npz", "denoiser_small.npz"])
 def test_stacked_calls_match_reference_autograd(nat, golden, case):
     """T calls of one Linear stacked into one K=T contraction == the reference's per-sample grads."""
