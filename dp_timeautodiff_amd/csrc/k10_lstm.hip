@@ -11,23 +11,27 @@
 // carried dh / dc never leave registers.  The backward kernel writes the pre-activation gradient dpre [B,T,4H]: it is
 // at once dL/dxg (autograd continues into ih, whose hook hands (x, dpre) to K1) and the `G` operand of hh's
 // per-sample-gradient contraction with A = h_{t-1} [B,T,H], which the forward kernel stored.
-// H need not be a multiple of 4 (the reference uses H = 250): row accesses fall back to 8-byte / scalar pieces.
+// H need not be a multiple of 4 (the reference uses H = 250): full groups of 4 are unaligned 16-byte accesses, the
+// ragged last group of a row goes element by element.
 #include "rnn_tile.h"
 
 namespace {
 
+// rows of width H = 250 start 8-byte aligned at best: gfx950 global accesses need dword alignment only, so a full
+// group of 4 is one 16-byte access whatever its address (H=250 ran 20-24 % slower with scalar pieces)
+typedef float f32x4u __attribute__((ext_vector_type(4), aligned(4)));
 __device__ __forceinline__ f32x4 ldv(const float* p, int nv) {
+    if (nv >= 4) return *reinterpret_cast<const f32x4u*>(p);
     f32x4 v = {0.f, 0.f, 0.f, 0.f};
-    if (nv >= 4 && ((uintptr_t)p & 15) == 0) return ld4(p);
 #pragma unroll
-    for (int e = 0; e < 4; ++e)
+    for (int e = 0; e < 3; ++e)
         if (e < nv) v[e] = p[e];
     return v;
 }
 __device__ __forceinline__ void stv(float* p, f32x4 v, int nv) {
-    if (nv >= 4 && ((uintptr_t)p & 15) == 0) { st4(p, v); return; }
+    if (nv >= 4) { *reinterpret_cast<f32x4u*>(p) = v; return; }
 #pragma unroll
-    for (int e = 0; e < 4; ++e)
+    for (int e = 0; e < 3; ++e)
         if (e < nv) p[e] = v[e];
 }
 __device__ __forceinline__ void lds_colv(float* s, int o, int j, f32x4 v, int nv) {

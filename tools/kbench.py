@@ -50,6 +50,20 @@ def bench_gru(B, T, H, G=1):
     print(f"K8 G={G} B={B} T={T} H={H}: fwd {ms_f*1e3:8.1f} us ({flops/ms_f/1e9:5.1f} TFLOP/s)  bwd {ms_b*1e3:8.1f} us "
           f"({flops/ms_b/1e9:5.1f} TFLOP/s)  per step fwd {ms_f*1e3/T:6.2f} us bwd {ms_b*1e3/T:6.2f} us  packs {ms_p*1e3:5.1f} us")
 
+def bench_lstm(B, T, H, G=2):
+    xgs = [torch.randn(B, T, 4 * H, device="cuda") for _ in range(G)]
+    W = [torch.randn(4 * H, H, device="cuda") / H ** 0.5 for _ in range(G)]
+    b = [torch.zeros(4 * H, device="cuda") for _ in range(G)]
+    P = nat.lstm_pack_forward(W, H); Pt = nat.lstm_pack_backward(W, H)
+    rm = 2 if G > 1 else 0
+    out, gates, C, Hprev = nat.lstm_forward(xgs, None, None, b, P, rm)
+    ms_f = timeit(lambda: nat.lstm_forward(xgs, None, None, b, P, rm), iters=5, warm=1)
+    douts = [torch.randn(B, T, H, device="cuda") for _ in range(G)]
+    ms_b = timeit(lambda: nat.lstm_backward(douts, None, gates, C, Pt, rm, False), iters=5, warm=1)
+    flops = 2.0 * G * B * T * 4 * H * H
+    print(f"K10 G={G} B={B} T={T} H={H}: fwd {ms_f*1e3:8.1f} us ({flops/ms_f/1e9:5.1f} TFLOP/s)  bwd {ms_b*1e3:8.1f} us "
+          f"({flops/ms_b/1e9:5.1f} TFLOP/s)  per step fwd {ms_f*1e3/T:6.2f} us bwd {ms_b*1e3/T:6.2f} us")
+
 
 if __name__ == "__main__":
     which = sys.argv[1] if len(sys.argv) > 1 else "all"
@@ -75,6 +89,13 @@ if __name__ == "__main__":
         bench_reduce(1024, 824448)
         bench_reduce(2048, 2830272)
         bench_reduce(256, 12292096)
+    if which in ("all", "k10"):
+        bench_lstm(4096, 48, 250)
+        bench_lstm(4096, 48, 256)
+        bench_lstm(2048, 48, 250)
+        bench_lstm(2048, 48, 256)
+        bench_lstm(4096, 48, 128)
+        bench_lstm(512, 48, 250)
     if which in ("all", "k8"):
         bench_gru(64, 24, 200)
         bench_gru(64, 24, 200, G=2)
