@@ -65,7 +65,11 @@ __device__ __forceinline__ void mfma_tile4(f32x4 (&a)[4], const f32x4* __restric
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
                 DPK_MFMA4(a[g], w[g][s], bc.b0, bc.b1, bc.b2, bc.b3);
+#ifdef DPK_LAB_W_L1
+                w[g][s] = pw[g][((kg + s + GPF) & 1) * 64];
+#else
                 w[g][s] = pw[g][(kg + s + GPF) * 64];
+#endif
             }
             __builtin_amdgcn_sched_barrier(0);
             bc = bn;

@@ -14,7 +14,7 @@ with open(out_csv, "w", newline="") as f:
         short = name if len(name) < 160 else name[:157] + "..."
         w.writerow([short, r["Calls"], r["TotalDurationNs"], r["AverageNs"], r["Percentage"], r["MinNs"], r["MaxNs"]])
 ours = [r for r in rows if "anonymous namespace" in r["Name"] and any(k in r["Name"] for k in
-        ("linear_gs", "clip_reduce", "finalize", "clip_factor", "embedding_gs", "layernorm_gs", "noise_scale", "normsq", "adam", "gru"))]
+        ("linear_gs", "clip_reduce", "finalize", "clip_factor", "embedding_gs", "layernorm_gs", "noise_scale", "normsq", "adam", "gru", "lstm", "poisson"))]
 tot = sum(float(r["TotalDurationNs"]) for r in rows)
 with open(os.path.join(root, "profiles", f"{tag}_kernel_stats.md"), "w") as f:
     f.write(f"# rocprofv3 --kernel-trace --stats summary ({tag})\n\n")
