@@ -28,7 +28,7 @@ EXPORTS = {
     "dpk_linear_grad_sample": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int,
                                        c_int, c_int, c_int, c_int, c_int64, c_int, c_float, c_void_p]),
     "dpk_linear_grad_sample_group": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_int64,
-                                             c_int, c_int, c_int, c_int, c_int64, c_int, c_float, c_void_p]),
+                                             c_int, c_int, c_int, c_int, c_int64, c_int, c_int, c_float, c_void_p]),
     "dpk_embedding_grad_sample": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int,
                                           c_int, c_int, c_int, c_int, c_int64, c_float, c_void_p]),
     "dpk_layernorm_grad_sample": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int,
@@ -53,10 +53,9 @@ EXPORTS = {
     "dpk_lstm_backward": (c_int, [c_void_p] * 8 + [c_int] * 5 + [c_void_p]),
     "dpk_gru_pack_floats": (c_int64, [c_int, c_int]),
     "dpk_gru_pack_forward": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p]),
-    "dpk_gru_pack_backward": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int,
-                                      c_void_p]),
+    "dpk_gru_pack_backward": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_int, c_int, c_void_p]),
     "dpk_gru_forward": (c_int, [c_void_p] * 12 + [c_int, c_int, c_int, c_int, c_void_p]),
-    "dpk_gru_backward": (c_int, [c_void_p] * 15 + [c_int, c_int, c_int, c_int, c_void_p]),
+    "dpk_gru_backward": (c_int, [c_void_p] * 10 + [c_int, c_int, c_int, c_int, c_void_p]),
 }
 
 
@@ -139,6 +138,8 @@ def normsq_slots(P: int) -> int:
 def linear_grad_sample(A, G, gs_w: FlatView, gs_b: Optional[FlatView], part: torch.Tensor, slot0: int,
                        g_scale: float, ld_w: Optional[int] = None):
     _req(A, "A"); _req(G, "G"); _req(part, "normsq_part"); _req(gs_w.base, "arena")
+    if G.dim() == 3 and not G.is_contiguous() and _rows_ld(G) is not None:  # column block of a wider buffer
+        return linear_grad_sample_group([(A, G, gs_w, gs_b, slot0)], part, g_scale, ld_w)
     if A.dim() != 3 or G.dim() != 3 or not A.is_contiguous() or not G.is_contiguous():
         raise DpkError("A and G must be contiguous [B,T,features]")
     B, T, in_f = A.shape
@@ -163,24 +164,34 @@ def linear_grad_sample(A, G, gs_w: FlatView, gs_b: Optional[FlatView], part: tor
 K1_MAX_JOBS = 8
 
 
+def _rows_ld(G):
+    """Row stride of a [B,T,out] operand whose rows may be column blocks of a wider buffer; None if unsupported."""
+    if G.dim() != 3 or G.stride(2) != 1 or G.stride(0) != G.shape[1] * G.stride(1) or G.stride(1) < G.shape[2]:
+        return None
+    return G.stride(1)
+
+
 def linear_grad_sample_group(jobs, part: torch.Tensor, g_scale: float, ld_w: Optional[int] = None):
-    """jobs: list of (A, G, gs_w, gs_b or None, slot0) of ONE shape; one launch (dpk_linear_grad_sample_group)."""
+    """jobs: list of (A, G, gs_w, gs_b or None, slot0) of ONE shape; one launch (dpk_linear_grad_sample_group).
+    G may be a column block of a wider [B,T,W] buffer (row stride ld_g = W, the same for every job)."""
     if not 1 <= len(jobs) <= K1_MAX_JOBS:
         raise DpkError(f"1..{K1_MAX_JOBS} jobs per group, got {len(jobs)}")
     A0, G0, w0, _, _ = jobs[0]
     _req(part, "normsq_part")
     if A0.dim() != 3 or G0.dim() != 3:
-        raise DpkError("A and G must be contiguous [B,T,features]")
+        raise DpkError("A and G must be [B,T,features]")
     B, T, in_f = A0.shape
     out_f = G0.shape[2]
+    ld_g = _rows_ld(G0)
     ld_w = in_f if ld_w is None else int(ld_w)
     if part.shape[0] < B or part.dim() != 2 or part.stride(1) != 1:
         raise DpkError("partial buffer has fewer rows than the batch")
     for A, G, gs_w, gs_b, slot0 in jobs:
         _req(A, "A"); _req(G, "G"); _req(gs_w.base, "arena")
-        if tuple(A.shape) != (B, T, in_f) or tuple(G.shape) != (B, T, out_f) or not A.is_contiguous() \
-                or not G.is_contiguous():
-            raise DpkError("all jobs of a group must share one contiguous [B,T,in] / [B,T,out] shape")
+        if tuple(A.shape) != (B, T, in_f) or tuple(G.shape) != (B, T, out_f) or not A.is_contiguous():
+            raise DpkError("all jobs of a group must share one [B,T,in] / [B,T,out] shape, A contiguous")
+        if ld_g is None or _rows_ld(G) != ld_g:
+            raise DpkError("G must be [B,T,out] rows of one common stride (contiguous, or a column block)")
         if ld_w < in_f or gs_w.numel != ld_w * out_f or (gs_b is not None and gs_b.numel != out_f):
             raise DpkError("grad-sample window does not match the layer shape")
         if gs_w.base.shape[0] < B or gs_w.stride != w0.stride:
@@ -196,7 +207,7 @@ def linear_grad_sample_group(jobs, part: torch.Tensor, g_scale: float, ld_w: Opt
     pb = arr([None if j[3] is None else j[3].ptr.value for j in jobs])
     slots = (c_int * n)(*[int(j[4]) for j in jobs])
     rc = load().dpk_linear_grad_sample_group(pa, pg, pw, pb, slots, n, _ptr(part), part.stride(0), B, T, in_f, out_f,
-                                             w0.stride, ld_w, float(g_scale), _stream())
+                                             w0.stride, ld_w, ld_g, float(g_scale), _stream())
     _check(rc, "dpk_linear_grad_sample_group")
 
 
@@ -342,8 +353,9 @@ def _gru_weights(weights, H):
 
 
 def gru_pack_forward(weights, H: int):
+    """Hidden halves W[:, H:] of the gates in MFMA fragment order: Pz, Pr, Pn [G, packed(H,H)]."""
     arr, G, dev = _gru_weights(weights, H)
-    n = gru_pack_floats(H, 2 * H)
+    n = gru_pack_floats(H, H)
     Pz, Pr, Pn = (torch.empty(G, n, device=dev, dtype=torch.float32) for _ in range(3))
     _check(load().dpk_gru_pack_forward(arr, 2 * H, _ptr(Pz), _ptr(Pr), _ptr(Pn), H, G, _stream()),
            "dpk_gru_pack_forward")
@@ -351,20 +363,20 @@ def gru_pack_forward(weights, H: int):
 
 
 def gru_pack_backward(weights, H: int):
+    """Transposed hidden halves: Pnh [G, packed(H,H)], Pzrh [G, packed(H,2H)]."""
     arr, G, dev = _gru_weights(weights, H)
-    n1, n2 = gru_pack_floats(H, H), gru_pack_floats(H, 2 * H)
-    Pnx, Pnh = (torch.empty(G, n1, device=dev, dtype=torch.float32) for _ in range(2))
-    Pzrx, Pzrh = (torch.empty(G, n2, device=dev, dtype=torch.float32) for _ in range(2))
-    _check(load().dpk_gru_pack_backward(arr, 2 * H, _ptr(Pnx), _ptr(Pnh), _ptr(Pzrx), _ptr(Pzrh), H, G, _stream()),
-           "dpk_gru_pack_backward")
-    return Pnx, Pnh, Pzrx, Pzrh
+    Pnh = torch.empty(G, gru_pack_floats(H, H), device=dev, dtype=torch.float32)
+    Pzrh = torch.empty(G, gru_pack_floats(H, 2 * H), device=dev, dtype=torch.float32)
+    _check(load().dpk_gru_pack_backward(arr, 2 * H, _ptr(Pnh), _ptr(Pzrh), H, G, _stream()), "dpk_gru_pack_backward")
+    return Pnh, Pzrh
 
 
-def gru_forward(xps, h0s, Pz, Pr, Pn, biases):
-    """xps: G tensors [B,T,H]; h0s: None or G tensors [B,H]; biases: 3 per GRU [H].
+def gru_forward(xps, xgs, h0s, Pz, Pr, Pn):
+    """xps: G tensors [B,T,H]; xgs: G tensors [B,T,3H] = x-side pre-activations (update | reset | new, biases
+    included); h0s: None or G tensors [B,H].
     Returns out, Z, R, N [G,B,T,H] and the stacked gate inputs Azr, An [G,B,T,2H]."""
     G = len(xps)
-    if G == 0 or G > GRU_MAX_G or len(biases) != 3 * G or (h0s is not None and len(h0s) != G):
+    if G == 0 or G > GRU_MAX_G or len(xgs) != G or (h0s is not None and len(h0s) != G):
         raise DpkError("gru_forward: inconsistent number of GRUs")
     _req(xps[0], "xp[0]")
     if xps[0].dim() != 3:
@@ -373,24 +385,25 @@ def gru_forward(xps, h0s, Pz, Pr, Pn, biases):
     if B == 0 or T == 0:
         raise DpkError("gru_forward: empty batch / sequence")
     xa = _ptr_array(xps, "xp", (B, T, H))
+    ga = _ptr_array(xgs, "xg", (B, T, 3 * H))
     ha = None if h0s is None else _ptr_array(h0s, "h0", (B, H))
-    ba = _ptr_array(biases, "bias", (H,))
-    n_pack = gru_pack_floats(H, 2 * H)
+    n_pack = gru_pack_floats(H, H)
     for t, n in ((Pz, "Pz"), (Pr, "Pr"), (Pn, "Pn")):
         _req(t, n)
         if tuple(t.shape) != (G, n_pack) or not t.is_contiguous():
-            raise DpkError(f"gru_forward: {n} is not [G, packed(H,2H)]")
+            raise DpkError(f"gru_forward: {n} is not [G, packed(H,H)]")
     dev = xps[0].device
     out, Z, R, N = (torch.empty(G, B, T, H, device=dev, dtype=torch.float32) for _ in range(4))
     Azr, An = (torch.empty(G, B, T, 2 * H, device=dev, dtype=torch.float32) for _ in range(2))
-    rc = load().dpk_gru_forward(xa, ha, _ptr(Pz), _ptr(Pr), _ptr(Pn), ba, _ptr(out), _ptr(Z), _ptr(R), _ptr(N),
+    rc = load().dpk_gru_forward(xa, ga, ha, _ptr(Pz), _ptr(Pr), _ptr(Pn), _ptr(out), _ptr(Z), _ptr(R), _ptr(N),
                                 _ptr(Azr), _ptr(An), B, T, H, G, _stream())
     _check(rc, "dpk_gru_forward")
     return out, Z, R, N, Azr, An
 
 
-def gru_backward(douts, dhTs, Z, R, N, Azr, Pnx, Pnh, Pzrx, Pzrh, want_dh0: bool):
-    """douts: G tensors [B,T,H] (None entries = zeros).  Returns dxp, Gz, Gr, Gn [G,B,T,H], dh0 [G,B,H] or None."""
+def gru_backward(douts, dhTs, Z, R, N, Azr, Pnh, Pzrh, want_dh0: bool):
+    """douts: G tensors [B,T,H] (None entries = zeros).  Returns G3 [G,B,T,3H] = [Gz | Gr | Gn] (the gates'
+    pre-activation gradients = dL/dxg), dh0 [G,B,H] or None."""
     _req(Z, "Z")
     if Z.dim() != 4 or not Z.is_contiguous():
         raise DpkError("gru_backward: Z must be contiguous [G,B,T,H]")
@@ -404,20 +417,18 @@ def gru_backward(douts, dhTs, Z, R, N, Azr, Pnx, Pnh, Pzrx, Pzrh, want_dh0: bool
     _req(Azr, "Azr")
     if tuple(Azr.shape) != (G, B, T, 2 * H) or not Azr.is_contiguous():
         raise DpkError("gru_backward: Azr must be contiguous [G,B,T,2H]")
-    n1, n2 = gru_pack_floats(H, H), gru_pack_floats(H, 2 * H)
-    for t, n, cnt in ((Pnx, "Pnx", n1), (Pnh, "Pnh", n1), (Pzrx, "Pzrx", n2), (Pzrh, "Pzrh", n2)):
+    for t, n, cnt in ((Pnh, "Pnh", gru_pack_floats(H, H)), (Pzrh, "Pzrh", gru_pack_floats(H, 2 * H))):
         _req(t, n)
         if tuple(t.shape) != (G, cnt) or not t.is_contiguous():
             raise DpkError(f"gru_backward: {n} has the wrong packed size")
     da = _ptr_array(douts, "dout", (B, T, H), allow_none=True)
     ha = None if dhTs is None else _ptr_array(dhTs, "dhT", (B, H), allow_none=True)
-    dxp, Gz, Gr, Gn = (torch.empty_like(Z) for _ in range(4))
+    G3 = torch.empty(G, B, T, 3 * H, device=Z.device, dtype=torch.float32)
     dh0 = torch.empty(G, B, H, device=Z.device, dtype=torch.float32) if want_dh0 else None
-    rc = load().dpk_gru_backward(da, ha, _ptr(Z), _ptr(R), _ptr(N), _ptr(Azr), _ptr(Pnx), _ptr(Pnh), _ptr(Pzrx),
-                                 _ptr(Pzrh), _ptr(dxp), _ptr(Gz), _ptr(Gr), _ptr(Gn), _ptr(dh0), B, T, H, G,
-                                 _stream())
+    rc = load().dpk_gru_backward(da, ha, _ptr(Z), _ptr(R), _ptr(N), _ptr(Azr), _ptr(Pnh), _ptr(Pzrh), _ptr(G3),
+                                 _ptr(dh0), B, T, H, G, _stream())
     _check(rc, "dpk_gru_backward")
-    return dxp, Gz, Gr, Gn, dh0
+    return G3, dh0
 
 
 # ---- K10: fused DPLSTM recurrence -----------------------------------------------------------------------------------

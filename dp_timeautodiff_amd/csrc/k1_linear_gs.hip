@@ -35,8 +35,8 @@ typedef float f32x4u __attribute__((ext_vector_type(4), aligned(4)));  // global
 
 template <int W, int NTHR>
 __device__ __forceinline__ void stage_rows(float* __restrict__ s, const float* __restrict__ g, int t0, int rows,
-                                           int T, int c0, int dim, float scale) {
-    // s[rows][W]  <-  scale * g[t0 + r][c0 + c]   (zero outside [0,T) x [0,dim)).  One 16-byte global load per 4
+                                           int T, int c0, int dim, int ld, float scale) {
+    // s[rows][W]  <-  scale * g[(t0 + r) * ld + c0 + c]   (zero outside [0,T) x [0,dim)).  One 16-byte global load per 4
     // columns whatever the row alignment (gfx950 global loads need dword alignment only); the last, partial group
     // of a row is read element by element so nothing past the row end is touched.
     constexpr int W4 = W / 4;
@@ -46,7 +46,7 @@ __device__ __forceinline__ void stage_rows(float* __restrict__ s, const float* _
         const int t = t0 + r;
         f32x4 v = {0.f, 0.f, 0.f, 0.f};
         if (t < T) {
-            const float* src = g + (int64_t)t * dim + c0 + c;
+            const float* src = g + (int64_t)t * ld + c0 + c;
             const int left = dim - (c0 + c);
             if (left >= 4) {
                 v = *reinterpret_cast<const f32x4u*>(src);
@@ -70,7 +70,7 @@ __global__ void __launch_bounds__(NW * 64) linear_gs_kernel(const float* __restr
                                                            float* __restrict__ GSw, float* __restrict__ GSb,
                                                            float* __restrict__ normsq_part, int64_t part_stride,
                                                            int slot0, int B, int T, int in_f, int out_f,
-                                                           int64_t gs_stride, int ld_w, float g_scale,
+                                                           int64_t gs_stride, int ld_w, int ld_g, float g_scale,
                                                            int tiles_m, int tiles_n) {
     constexpr int NTHR = NW * 64;
     constexpr int NCG = CS / (32 * NT);        // column groups per tile
@@ -102,7 +102,7 @@ __global__ void __launch_bounds__(NW * 64) linear_gs_kernel(const float* __restr
     const int lh = lane >> 5;
 
     const float* Ab = A + (int64_t)b * T * in_f;
-    const float* Gb = G + (int64_t)b * T * out_f;
+    const float* Gb = G + (int64_t)b * T * ld_g;
 
     float bias_acc = 0.f;
     const bool do_bias = (GSb != nullptr) && (tn == 0) && ((int)threadIdx.x < RS);
@@ -136,8 +136,8 @@ __global__ void __launch_bounds__(NW * 64) linear_gs_kernel(const float* __restr
 
     if constexpr (STREAM) {
         const int rows2 = (T + 1) & ~1;  // MFMA consumes k in pairs; the pad row is zero-filled
-        stage_rows<RS, NTHR>(sG, Gb, 0, rows2, T, m0, out_f, g_scale);
-        stage_rows<CS, NTHR>(sA, Ab, 0, rows2, T, n0, in_f, 1.0f);
+        stage_rows<RS, NTHR>(sG, Gb, 0, rows2, T, m0, out_f, ld_g, g_scale);
+        stage_rows<CS, NTHR>(sA, Ab, 0, rows2, T, n0, in_f, in_f, 1.0f);
         __syncthreads();
         for (int u = wave; u < UNITS; u += NW) {
             const int mr = u / NCG, cg = u - mr * NCG;
@@ -172,8 +172,8 @@ __global__ void __launch_bounds__(NW * 64) linear_gs_kernel(const float* __restr
             int rows = T - t0;
             if (rows > TK) rows = TK;
             const int rows2 = (rows + 1) & ~1;
-            stage_rows<RS, NTHR>(sG, Gb, t0, rows2, T, m0, out_f, g_scale);
-            stage_rows<CS, NTHR>(sA, Ab, t0, rows2, T, n0, in_f, 1.0f);
+            stage_rows<RS, NTHR>(sG, Gb, t0, rows2, T, m0, out_f, ld_g, g_scale);
+            stage_rows<CS, NTHR>(sA, Ab, t0, rows2, T, n0, in_f, in_f, 1.0f);
             __syncthreads();
 #pragma unroll
             for (int k = 0; k < U; ++k) {
@@ -223,10 +223,10 @@ __global__ void __launch_bounds__(NW * 64) linear_gs_kernel(const float* __restr
 // unit and streams it out at once, as in STREAM mode.
 __device__ __forceinline__ void lds_only_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
-__device__ __forceinline__ f32x4 fetch4(const float* __restrict__ g, int t, int T, int col, int dim) {
+__device__ __forceinline__ f32x4 fetch4(const float* __restrict__ g, int t, int T, int col, int dim, int ld) {
     f32x4 v = {0.f, 0.f, 0.f, 0.f};
     if (t < T) {
-        const float* src = g + (int64_t)t * dim + col;
+        const float* src = g + (int64_t)t * ld + col;
         const int left = dim - col;
         if (left >= 4) {
             v = *reinterpret_cast<const f32x4u*>(src);
@@ -253,7 +253,7 @@ struct K1Jobs {
 template <int NW, int RS, int CS, int NT, int NG, int NA, bool NTS>
 __global__ void __launch_bounds__(NW * 64) linear_gs_persist_kernel(
     const K1Jobs jobs, float* __restrict__ normsq_part, int64_t part_stride, int B, int T, int in_f, int out_f,
-    int64_t gs_stride, int ld_w, float g_scale, int tiles_m, int tiles_n) {
+    int64_t gs_stride, int ld_w, int ld_g, float g_scale, int tiles_m, int tiles_n) {
     constexpr int NTHR = NW * 64;
     constexpr int NCG = CS / (32 * NT);
     constexpr int UNITS = (RS / 32) * NCG;
@@ -287,19 +287,19 @@ __global__ void __launch_bounds__(NW * 64) linear_gs_persist_kernel(
         const int b = (int)(rem / ntile) * 8 + xcd;
         const int tile = (int)(rem % ntile);
         const int tm = tile / tiles_n, tn = tile - tm * tiles_n;
-        const float* Gb = jobs.G[job] + (int64_t)b * T * out_f;
+        const float* Gb = jobs.G[job] + (int64_t)b * T * ld_g;
         const float* Ab = jobs.A[job] + (int64_t)b * T * in_f;
 #pragma unroll
         for (int k = 0; k < NG; ++k) {
             const int idx = threadIdx.x + k * NTHR;
             const int t = idx / R4, c = (idx - t * R4) * 4;
-            rg[k] = fetch4(Gb, idx < totG ? t : T, T, tm * RS + c, out_f);
+            rg[k] = fetch4(Gb, idx < totG ? t : T, T, tm * RS + c, out_f, ld_g);
         }
 #pragma unroll
         for (int k = 0; k < NA; ++k) {
             const int idx = threadIdx.x + k * NTHR;
             const int t = idx / C4, c = (idx - t * C4) * 4;
-            ra[k] = fetch4(Ab, idx < totA ? t : T, T, tn * CS + c, in_f);
+            ra[k] = fetch4(Ab, idx < totA ? t : T, T, tn * CS + c, in_f, in_f);
         }
     };
 
@@ -436,10 +436,10 @@ namespace {
 
 int k1_launch(const float* const* A, const float* const* G, float* const* GSw, float* const* GSb, const int* slot0,
               int n_jobs, float* normsq_part, int64_t part_stride, int B, int T, int in_f, int out_f,
-              int64_t gs_stride, int ld_w, float g_scale, void* stream) {
+              int64_t gs_stride, int ld_w, int ld_g, float g_scale, void* stream) {
     if (!A || !G || !GSw || !slot0 || !normsq_part || n_jobs < 1 || n_jobs > DPK_K1_MAX_JOBS) return DPK_EINVAL;
     if (B < 0 || T <= 0 || in_f <= 0 || out_f <= 0) return DPK_EINVAL;
-    if (ld_w < in_f || gs_stride < (int64_t)ld_w * out_f) return DPK_EINVAL;
+    if (ld_w < in_f || gs_stride < (int64_t)ld_w * out_f || ld_g < out_f) return DPK_EINVAL;
     const Plan p = pick_plan(in_f, out_f);
     const int tiles_m = (out_f + p.rs - 1) / p.rs;
     const int tiles_n = (in_f + p.cs - 1) / p.cs;
@@ -481,7 +481,7 @@ int k1_launch(const float* const* A, const float* const* G, float* const* GSw, f
             if (e_ != hipSuccess) return (int)e_;                                                                \
         }                                                                                                        \
         hipLaunchKernelGGL(kfn, pgrid, dim3(512), lds, s, jobs, normsq_part, part_stride, B, T, in_f, out_f,     \
-                           gs_stride, ld_w, g_scale, tiles_m, tiles_n);                                          \
+                           gs_stride, ld_w, ld_g, g_scale, tiles_m, tiles_n);                                          \
     } while (0)
         if (T <= 32) {
             if (nt_store) DPK_K1_PGO(2, 4, true); else DPK_K1_PGO(2, 4, false);
@@ -504,7 +504,7 @@ int k1_launch(const float* const* A, const float* const* G, float* const* GSw, f
     for (int j = 0; j < n_jobs; ++j)                                                                             \
         hipLaunchKernelGGL((linear_gs_kernel<NW, RS, CS, NT, ST, NTS>), grid, dim3(NW * 64), lds, s, A[j], G[j], \
                            GSw[j], GSb ? GSb[j] : nullptr, normsq_part, part_stride, slot0[j], B, T, in_f,      \
-                           out_f, gs_stride, ld_w, g_scale, tiles_m, tiles_n)
+                           out_f, gs_stride, ld_w, ld_g, g_scale, tiles_m, tiles_n)
 #define DPK_K1_LAUNCH(NW, RS, CS, NT)                                                                          \
     do {                                                                                                       \
         const size_t lds = ((size_t)lds_rows * (RS + CS) + NW) * sizeof(float);                                \
@@ -531,13 +531,13 @@ extern "C" int dpk_linear_grad_sample(const float* A, const float* G, float* GSw
                                       int64_t part_stride, int slot0, int B, int T, int in_f, int out_f,
                                       int64_t gs_stride, int ld_w, float g_scale, void* stream) {
     return k1_launch(&A, &G, &GSw, GSb ? &GSb : nullptr, &slot0, 1, normsq_part, part_stride, B, T, in_f, out_f,
-                     gs_stride, ld_w, g_scale, stream);
+                     gs_stride, ld_w, out_f, g_scale, stream);
 }
 
 extern "C" int dpk_linear_grad_sample_group(const float* const* A, const float* const* G, float* const* GSw,
                                             float* const* GSb, const int* slot0, int n_jobs, float* normsq_part,
                                             int64_t part_stride, int B, int T, int in_f, int out_f,
-                                            int64_t gs_stride, int ld_w, float g_scale, void* stream) {
+                                            int64_t gs_stride, int ld_w, int ld_g, float g_scale, void* stream) {
     return k1_launch(A, G, GSw, GSb, slot0, n_jobs, normsq_part, part_stride, B, T, in_f, out_f, gs_stride, ld_w,
-                     g_scale, stream);
+                     ld_g, g_scale, stream);
 }

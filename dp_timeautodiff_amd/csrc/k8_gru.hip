@@ -23,20 +23,45 @@
 
 namespace {
 
+// MFMA helper for one phase over TPW tiles of a wave sharing the LDS operand: pairs of tiles run as two accumulator
+// chains (mfma_tile2); a single (or odd last) tile splits K over two chains instead (mfma_tile_ks).
+template <int TPW, int GPF>
+__device__ __forceinline__ void phase_tiles(f32x4 (&acc)[TPW], const f32x4* __restrict__ P, int64_t tile_stride,
+                                            const float* __restrict__ sB, int KG, int NT, int wave, int lane) {
+    if constexpr (TPW == 1) {
+        if (wave < NT) mfma_tile_ks<GPF>(acc[0], P + (int64_t)wave * tile_stride, sB, KG, lane);
+    } else {
+#pragma unroll
+        for (int i = 0; i < TPW; i += 2) {
+            const int ot0 = wave + GNW * i, ot1 = wave + GNW * (i + 1);
+            if (ot1 < NT)
+                mfma_tile2<GPF>(acc[i], acc[i + 1], P + (int64_t)ot0 * tile_stride, P + (int64_t)ot1 * tile_stride, sB, KG,
+                                lane);
+            else if (ot0 < NT)
+                mfma_tile_ks<GPF>(acc[i], P + (int64_t)ot0 * tile_stride, sB, KG, lane);
+        }
+    }
+}
+
+// Forward.  The x half of every gate (W[:, :H] x_t + b, all T steps) is ONE ordinary GEMM outside the kernel
+// (xg [B,T,3H], column blocks z | r | n): only the h half (K = H) is sequential, which halves the MFMA work on the
+// T-step latency chain and removes the per-step x_t -> LDS transpose and its barrier.  x_t itself only passes through
+// (global -> global) into the x halves of the gates' stacked activations Azr / An that K1 contracts.
 template <int TPW, bool PRE>
-__global__ void __launch_bounds__(GNW * 64) gru_fwd_kernel(GPtrs xps, GPtrs h0s, const f32x4* __restrict__ Pz,
+__global__ void __launch_bounds__(GNW * 64) gru_fwd_kernel(GPtrs xps, GPtrs xgs, GPtrs h0s, const f32x4* __restrict__ Pz,
                                                            const f32x4* __restrict__ Pr, const f32x4* __restrict__ Pn,
-                                                           GPtrs3 biases, float* __restrict__ out,
-                                                           float* __restrict__ Z, float* __restrict__ R,
-                                                           float* __restrict__ N, float* __restrict__ Azr,
-                                                           float* __restrict__ An, int B, int T, int H) {
+                                                           float* __restrict__ out, float* __restrict__ Z,
+                                                           float* __restrict__ R, float* __restrict__ N,
+                                                           float* __restrict__ Azr, float* __restrict__ An, int B, int T,
+                                                           int H) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     constexpr int NTH = GNW * 64;
-    const int KG = (2 * H + 15) / 16;
+    constexpr int GPF = TPW < 4 ? 4 : 2;
+    const int KG = (H + 15) / 16;
     const int K16 = KG * 16;
-    float* bufA = smem;               // [K16][16]  rows: x_t (H) | h_{t-1} (H) | zero pad
-    float* bufB = smem + K16 * GBT;   // [K16][16]  rows: x_t (H) | r*h_{t-1} (H) | zero pad
-    const int NT = (H + 15) / 16;
+    float* bufA = smem;               // [K16][16]  h_{t-1}, k-major, zero padded
+    float* bufB = smem + K16 * GBT;   // [K16][16]  r * h_{t-1}
+    const int NT = KG;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int j = lane & 15, q = lane >> 4;
     const int b0 = blockIdx.x * GBT;
@@ -47,124 +72,143 @@ __global__ void __launch_bounds__(GNW * 64) gru_fwd_kernel(GPtrs xps, GPtrs h0s,
     // this kernel writes (and the packed weights) has a leading [G] dimension
     const int gi = blockIdx.y;
     const float* __restrict__ xp = xps.p[gi];
+    const float* __restrict__ xg = xgs.p[gi];
     const float* __restrict__ h0 = h0s.p[gi];
-    const float* __restrict__ bz = biases.p[3 * gi], * __restrict__ br = biases.p[3 * gi + 1],
-                             * __restrict__ bn = biases.p[3 * gi + 2];
     {
         const int64_t g = gi, gx = g * B * T * H, gp = g * NT * KG * 64;
         out += gx; Z += gx; R += gx; N += gx; Azr += 2 * gx; An += 2 * gx;
         Pz += gp; Pr += gp; Pn += gp;
     }
+    const int64_t tile_stride = (int64_t)KG * 64;
     const int nx4 = GBT * H4;  // float4 elements of one x_t tile; <= TPW * NTH by construction of TPW
 
     for (int i = threadIdx.x; i < 2 * K16 * GBT; i += NTH) smem[i] = 0.f;
     __syncthreads();
 
-    f32x4 hreg[TPW], zreg[TPW], xpre[TPW];
+    const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
+    f32x4 hreg[TPW], zreg[TPW], gz[TPW], gr[TPW], gn[TPW];
 #pragma unroll
     for (int i = 0; i < TPW; ++i) {
         const int o = (wave + GNW * i) * 16 + q * 4;
-        hreg[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+        hreg[i] = zero4;
         if (wave + GNW * i < NT && o < H && bvalid && h0) hreg[i] = ld4(h0 + (int64_t)b * H + o);
-        if (wave + GNW * i < NT && o < H) lds_col4(bufA, H + o, j, hreg[i]);
+        if (wave + GNW * i < NT && o < H) lds_col4(bufA, o, j, hreg[i]);
     }
+    auto load_g = [&](int t) {  // this lane's x-side pre-activations of step t (its accumulators' initial values)
+#pragma unroll
+        for (int i = 0; i < TPW; ++i) {
+            const int o = (wave + GNW * i) * 16 + q * 4;
+            gz[i] = gr[i] = gn[i] = zero4;
+            if (wave + GNW * i < NT && o < H && bvalid) {
+                const float* src = xg + ((int64_t)b * T + t) * 3 * H + o;
+                gz[i] = ld4(src);
+                gr[i] = ld4(src + H);
+                gn[i] = ld4(src + 2 * H);
+            }
+        }
+    };
+    // x_t only passes through, into the x half of the gates' stacked activations [x_t | h_{t-1}] and
+    // [x_t | r*h_{t-1}]: loaded before the phase-1 MFMAs, stored after them (the latency hides behind the MFMAs)
+    f32x4 xcp[TPW];
     auto load_x = [&](int t) {
 #pragma unroll
         for (int i = 0; i < TPW; ++i) {
             const int idx = threadIdx.x + i * NTH;
             const int jj = idx / H4, k4 = idx - jj * H4;
-            xpre[i] = f32x4{0.f, 0.f, 0.f, 0.f};
-            if (idx < nx4 && b0 + jj < B) xpre[i] = ld4(xp + ((int64_t)(b0 + jj) * T + t) * H + k4 * 4);
+            xcp[i] = zero4;
+            if (idx < nx4 && b0 + jj < B) xcp[i] = ld4(xp + ((int64_t)(b0 + jj) * T + t) * H + k4 * 4);
         }
     };
-    if (PRE) load_x(0);
-
-    for (int t = 0; t < T; ++t) {
-        if (!PRE) load_x(t);  // widest tiles: no registers to spare for the prefetch
-        // ---- x_t (prefetched during the previous step) -> both operand buffers, transposed to k-major ------
+    auto store_x = [&](int t) {
 #pragma unroll
         for (int i = 0; i < TPW; ++i) {
             const int idx = threadIdx.x + i * NTH;
             const int jj = idx / H4, k4 = idx - jj * H4;
-            if (idx < nx4) {
-                lds_col4(bufA, k4 * 4, jj, xpre[i]);
-                lds_col4(bufB, k4 * 4, jj, xpre[i]);
-                if (b0 + jj < B) {  // x half of the gates' stacked activations [x_t | h_{t-1}] and [x_t | r*h_{t-1}]
-                    const int64_t ga = ((int64_t)(b0 + jj) * T + t) * 2 * H + k4 * 4;
-                    st4(Azr + ga, xpre[i]);
-                    st4(An + ga, xpre[i]);
-                }
+            if (idx < nx4 && b0 + jj < B) {
+                const int64_t ga = ((int64_t)(b0 + jj) * T + t) * 2 * H + k4 * 4;
+                st4(Azr + ga, xcp[i]);
+                st4(An + ga, xcp[i]);
             }
         }
-        lds_barrier();
-        if (PRE && t + 1 < T) load_x(t + 1);
+    };
+    load_g(0);
+    lds_barrier();
+
+    for (int t = 0; t < T; ++t) {
         // ---- phase 1: z, r ; r*h -> bufB ------------------------------------------------------------------
+        f32x4 az[TPW], ar[TPW];
+#pragma unroll
+        for (int i = 0; i < TPW; ++i) { az[i] = gz[i]; ar[i] = gr[i]; }
+        load_x(t);
+#pragma unroll
+        for (int i = 0; i < TPW; ++i) {
+            const int ot = wave + GNW * i;
+            if (ot < NT) mfma_tile2<GPF>(az[i], ar[i], Pz + (int64_t)ot * tile_stride, Pr + (int64_t)ot * tile_stride, bufA,
+                                         KG, lane);
+        }
+        store_x(t);
+        f32x4 an[TPW];
 #pragma unroll
         for (int i = 0; i < TPW; ++i) {
             const int ot = wave + GNW * i;
             const int o = ot * 16 + q * 4;
-            if (ot < NT) {
-                f32x4 az = {0.f, 0.f, 0.f, 0.f}, ar = {0.f, 0.f, 0.f, 0.f};
-                if (o < H) { az = ld4(bz + o); ar = ld4(br + o); }
-                mfma_tile2<(TPW < 4 ? 4 : 2)>(az, ar, Pz + (int64_t)ot * KG * 64, Pr + (int64_t)ot * KG * 64, bufA, KG, lane);
-                if (o < H) {
-                    f32x4 z, r;
-                    z.x = sigmoidf_(az.x); z.y = sigmoidf_(az.y); z.z = sigmoidf_(az.z); z.w = sigmoidf_(az.w);
-                    r.x = sigmoidf_(ar.x); r.y = sigmoidf_(ar.y); r.z = sigmoidf_(ar.z); r.w = sigmoidf_(ar.w);
-                    const f32x4 rh = r * hreg[i];
-                    zreg[i] = z;
-                    lds_col4(bufB, H + o, j, rh);
-                    if (bvalid) {
-                        const int64_t g = ((int64_t)b * T + t) * H + o;
-                        st4(Z + g, z);
-                        st4(R + g, r);
-                        const int64_t ga = ((int64_t)b * T + t) * 2 * H + H + o;
-                        st4(Azr + ga, hreg[i]);
-                        st4(An + ga, rh);
-                    }
+            an[i] = gn[i];
+            if (ot < NT && o < H) {
+                f32x4 z, r;
+                z.x = sigmoidf_(az[i].x); z.y = sigmoidf_(az[i].y); z.z = sigmoidf_(az[i].z); z.w = sigmoidf_(az[i].w);
+                r.x = sigmoidf_(ar[i].x); r.y = sigmoidf_(ar[i].y); r.z = sigmoidf_(ar[i].z); r.w = sigmoidf_(ar[i].w);
+                const f32x4 rh = r * hreg[i];
+                zreg[i] = z;
+                lds_col4(bufB, o, j, rh);
+                if (bvalid) {
+                    const int64_t g = ((int64_t)b * T + t) * H + o;
+                    st4(Z + g, z);
+                    st4(R + g, r);
+                    const int64_t ga = ((int64_t)b * T + t) * 2 * H + H + o;
+                    st4(Azr + ga, hreg[i]);
+                    st4(An + ga, rh);
                 }
             }
         }
+        if (PRE && t + 1 < T) { load_g(t + 1); }  // gn of this step already moved to an[]
         lds_barrier();
         // ---- phase 2: n, h' ---------------------------------------------------------------------------------
+        phase_tiles<TPW, GPF>(an, Pn, tile_stride, bufB, KG, NT, wave, lane);
 #pragma unroll
         for (int i = 0; i < TPW; ++i) {
             const int ot = wave + GNW * i;
             const int o = ot * 16 + q * 4;
-            if (ot < NT) {
-                f32x4 an = {0.f, 0.f, 0.f, 0.f};
-                if (o < H) an = ld4(bn + o);
-                mfma_tile<(TPW < 4 ? 4 : 2)>(an, Pn + (int64_t)ot * KG * 64, bufB, KG, lane);
-                if (o < H) {
-                    f32x4 n;
-                    n.x = tanhf_(an.x); n.y = tanhf_(an.y); n.z = tanhf_(an.z); n.w = tanhf_(an.w);
-                    const f32x4 z = zreg[i];
-                    const f32x4 hn = (1.0f - z) * n + z * hreg[i];
-                    hreg[i] = hn;
-                    lds_col4(bufA, H + o, j, hn);  // phase-1 reads of bufA finished at the barrier above
-                    if (bvalid) {
-                        const int64_t g = ((int64_t)b * T + t) * H + o;
-                        st4(N + g, n);
-                        st4(out + g, hn);
-                    }
+            if (ot < NT && o < H) {
+                f32x4 n;
+                n.x = tanhf_(an[i].x); n.y = tanhf_(an[i].y); n.z = tanhf_(an[i].z); n.w = tanhf_(an[i].w);
+                const f32x4 z = zreg[i];
+                const f32x4 hn = (1.0f - z) * n + z * hreg[i];
+                hreg[i] = hn;
+                lds_col4(bufA, o, j, hn);  // phase-1 reads of bufA finished at the barrier above
+                if (bvalid) {
+                    const int64_t g = ((int64_t)b * T + t) * H + o;
+                    st4(N + g, n);
+                    st4(out + g, hn);
                 }
             }
         }
-        lds_barrier();  // bufB's x rows are rewritten at the top of the next step
+        if (!PRE && t + 1 < T) load_g(t + 1);
+        lds_barrier();  // h_t complete in bufA; bufB free for the next step's r*h
     }
 }
 
+// Backward.  Only the h halves of the transposed products are sequential (d(r*h) = Wn[:, H:]^T dn_pre, then
+// dh += [Wz[:, H:]; Wr[:, H:]]^T [dz_pre | dr_pre]); the x halves (dL/dx_t) are one GEMM over all T steps outside,
+// fed by the G_z | G_r | G_n rows (G3 [B,T,3H]) this kernel writes anyway for K1 (each gate a column block, ld_g = 3H).
 template <int TPW, bool PRE>
 __global__ void __launch_bounds__(GNW * 64) gru_bwd_kernel(GPtrs douts, GPtrs dhTs, const float* __restrict__ Z,
                                                            const float* __restrict__ R, const float* __restrict__ N,
-                                                           const float* __restrict__ Azr, const f32x4* __restrict__ Pnx,
-                                                           const f32x4* __restrict__ Pnh, const f32x4* __restrict__ Pzrx,
-                                                           const f32x4* __restrict__ Pzrh, float* __restrict__ dxp,
-                                                           float* __restrict__ Gz, float* __restrict__ Gr,
-                                                           float* __restrict__ Gn, float* __restrict__ dh0, int B, int T,
-                                                           int H) {
+                                                           const float* __restrict__ Azr, const f32x4* __restrict__ Pnh,
+                                                           const f32x4* __restrict__ Pzrh, float* __restrict__ G3,
+                                                           float* __restrict__ dh0, int B, int T, int H) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     constexpr int NTH = GNW * 64;
+    constexpr int GPF = TPW < 4 ? 4 : 2;
     const int KGn = (H + 15) / 16;       // K groups of GEMM1 (K = H: dn_pre)
     const int KGzr = (2 * H + 15) / 16;  // K groups of GEMM2 (K = 2H: dz_pre | dr_pre)
     float* sDn = smem;                   // [KGn*16][16]
@@ -178,16 +222,16 @@ __global__ void __launch_bounds__(GNW * 64) gru_bwd_kernel(GPtrs douts, GPtrs dh
     const float* __restrict__ dhT = dhTs.p[blockIdx.y];
     {
         const int64_t g = blockIdx.y, gx = g * B * T * H, gh = g * B * H;
-        Z += gx; R += gx; N += gx; Azr += 2 * gx; dxp += gx; Gz += gx; Gr += gx; Gn += gx;
+        Z += gx; R += gx; N += gx; Azr += 2 * gx; G3 += 3 * gx;
         if (dh0) dh0 += gh;
-        Pnx += g * NT * KGn * 64; Pnh += g * NT * KGn * 64;
-        Pzrx += g * NT * KGzr * 64; Pzrh += g * NT * KGzr * 64;
+        Pnh += g * NT * KGn * 64;
+        Pzrh += g * NT * KGzr * 64;
     }
 
     for (int i = threadIdx.x; i < (KGn + KGzr) * 16 * GBT; i += NTH) smem[i] = 0.f;
     __syncthreads();
 
-    f32x4 dhc[TPW], rreg[TPW], hpreg[TPW], accx[TPW];
+    f32x4 dhc[TPW], rreg[TPW], hpreg[TPW];
     f32x4 p_do[TPW], p_z[TPW], p_n[TPW], p_r[TPW], p_hp[TPW];  // next step's operands, in flight during the GEMMs
     const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
     auto load_step = [&](int t) {
@@ -229,10 +273,10 @@ __global__ void __launch_bounds__(GNW * 64) gru_bwd_kernel(GPtrs douts, GPtrs dh
                 const f32x4 dnp = dh * (1.0f - z) * (1.0f - n * n);
                 const f32x4 dzp = dh * (hp - n) * z * (1.0f - z);
                 dhc[i] = dh * z;
-                if (bvalid) {
-                    const int64_t g = ((int64_t)b * T + t) * H + o;
-                    st4(Gn + g, dnp);
-                    st4(Gz + g, dzp);
+                if (bvalid) {  // G3 row = [dz_pre | dr_pre | dn_pre]
+                    const int64_t g = ((int64_t)b * T + t) * 3 * H + o;
+                    st4(G3 + g + 2 * H, dnp);
+                    st4(G3 + g, dzp);
                 }
                 lds_col4(sDn, o, j, dnp);   // rows of batch columns beyond B are zeros (operands were zero)
                 lds_col4(sDzr, o, j, dzp);
@@ -240,39 +284,26 @@ __global__ void __launch_bounds__(GNW * 64) gru_bwd_kernel(GPtrs douts, GPtrs dh
         }
         lds_barrier();
         if (PRE && t > 0) load_step(t - 1);
-        // ---- GEMM1: d[x | r*h] = Wn^T dn_pre ; dr_pre -> sDzr --------------------------------------------------
+        // ---- GEMM1: d(r*h) = Wn[:, H:]^T dn_pre ; dr_pre -> sDzr ---------------------------------------------
+        f32x4 ah[TPW];
+#pragma unroll
+        for (int i = 0; i < TPW; ++i) ah[i] = zero4;
+        phase_tiles<TPW, GPF>(ah, Pnh, (int64_t)KGn * 64, sDn, KGn, NT, wave, lane);
 #pragma unroll
         for (int i = 0; i < TPW; ++i) {
             const int ot = wave + GNW * i;
             const int o = ot * 16 + q * 4;
-            accx[i] = zero4;
-            if (ot < NT) {
-                f32x4 ah = zero4;
-                mfma_tile2<(TPW < 4 ? 4 : 2)>(accx[i], ah, Pnx + (int64_t)ot * KGn * 64, Pnh + (int64_t)ot * KGn * 64, sDn, KGn, lane);
-                if (o < H) {
-                    const f32x4 r = rreg[i];
-                    const f32x4 drp = ah * hpreg[i] * r * (1.0f - r);
-                    dhc[i] += ah * r;
-                    lds_col4(sDzr, H + o, j, drp);
-                    if (bvalid) st4(Gr + ((int64_t)b * T + t) * H + o, drp);
-                }
+            if (ot < NT && o < H) {
+                const f32x4 r = rreg[i];
+                const f32x4 drp = ah[i] * hpreg[i] * r * (1.0f - r);
+                dhc[i] += ah[i] * r;
+                lds_col4(sDzr, H + o, j, drp);
+                if (bvalid) st4(G3 + ((int64_t)b * T + t) * 3 * H + H + o, drp);
             }
         }
         lds_barrier();
-        // ---- GEMM2: d[x | h] += [Wz;Wr]^T [dz_pre | dr_pre] ------------------------------------------------------
-#pragma unroll
-        for (int i = 0; i < TPW; ++i) {
-            const int ot = wave + GNW * i;
-            const int o = ot * 16 + q * 4;
-            if (ot < NT) {
-                f32x4 ah = zero4;
-                mfma_tile2<(TPW < 4 ? 4 : 2)>(accx[i], ah, Pzrx + (int64_t)ot * KGzr * 64, Pzrh + (int64_t)ot * KGzr * 64, sDzr, KGzr, lane);
-                if (o < H) {
-                    dhc[i] += ah;
-                    if (bvalid) st4(dxp + ((int64_t)b * T + t) * H + o, accx[i]);
-                }
-            }
-        }
+        // ---- GEMM2: dh += [Wz[:, H:]; Wr[:, H:]]^T [dz_pre | dr_pre] ---------------------------------------
+        phase_tiles<TPW, GPF>(dhc, Pzrh, (int64_t)KGzr * 64, sDzr, KGzr, NT, wave, lane);
         lds_barrier();  // sDn / sDzr are rewritten by the next (earlier) time step
     }
     if (dh0) {
@@ -310,85 +341,74 @@ extern "C" int dpk_gru_pack_forward(const float* const* W, int ld, float* Pz, fl
     if (!W || !Pz || !Pr || !Pn || H <= 0 || G <= 0 || ld < 2 * H) return DPK_EINVAL;
     if (G > GMAX) return DPK_ERANGE;
     if (!dpk_aligned16(Pz) || !dpk_aligned16(Pr) || !dpk_aligned16(Pn)) return DPK_EALIGN;
-    const int64_t n = dpk_gru_pack_floats(H, 2 * H);
+    const int64_t n = dpk_gru_pack_floats(H, H);
     PackJobs jobs{};
     float* dst[3] = {Pz, Pr, Pn};
     for (int g = 0; g < G; ++g)
         for (int k = 0; k < 3; ++k) {
             const int y = g * 3 + k;
             if (!W[y]) return DPK_EINVAL;
-            jobs.src[y] = W[y];
-            jobs.src2[y] = W[y];
+            jobs.src[y] = W[y] + H;  // the h half of the gate's [H, 2H] weight: columns H .. 2H-1
+            jobs.src2[y] = W[y] + H;
             jobs.dst[y] = dst[k] + g * n;
             jobs.coff[y] = 0;
-            jobs.K[y] = 2 * H;
+            jobs.K[y] = H;
             jobs.transposed[y] = 0;
         }
-    return rnn_launch_pack(jobs, 3 * G, ld, H, 2 * H, (hipStream_t)stream);
+    return rnn_launch_pack(jobs, 3 * G, ld, H, H, (hipStream_t)stream);
 }
 
-extern "C" int dpk_gru_pack_backward(const float* const* W, int ld, float* Pnx, float* Pnh, float* Pzrx, float* Pzrh,
-                                     int H, int G, void* stream) {
-    if (!W || !Pnx || !Pnh || !Pzrx || !Pzrh || H <= 0 || G <= 0 || ld < 2 * H) return DPK_EINVAL;
+extern "C" int dpk_gru_pack_backward(const float* const* W, int ld, float* Pnh, float* Pzrh, int H, int G,
+                                     void* stream) {
+    if (!W || !Pnh || !Pzrh || H <= 0 || G <= 0 || ld < 2 * H) return DPK_EINVAL;
     if (G > GMAX) return DPK_ERANGE;
-    if (!dpk_aligned16(Pnx) || !dpk_aligned16(Pnh) || !dpk_aligned16(Pzrx) || !dpk_aligned16(Pzrh)) return DPK_EALIGN;
+    if (!dpk_aligned16(Pnh) || !dpk_aligned16(Pzrh)) return DPK_EALIGN;
     const int64_t n1 = dpk_gru_pack_floats(H, H), n2 = dpk_gru_pack_floats(H, 2 * H);
     PackJobs jobs{};
     for (int g = 0; g < G; ++g) {
         const float *wz = W[3 * g], *wr = W[3 * g + 1], *wn = W[3 * g + 2];
         if (!wz || !wr || !wn) return DPK_EINVAL;
-        const float* src[4] = {wn, wn, wz, wz};
-        const float* src2[4] = {wn, wn, wr, wr};
-        float* dst[4] = {Pnx + g * n1, Pnh + g * n1, Pzrx + g * n2, Pzrh + g * n2};
-        const int coff[4] = {0, H, 0, H}, K[4] = {H, H, 2 * H, 2 * H};
-        for (int k = 0; k < 4; ++k) {
-            const int y = g * 4 + k;
+        // transposed jobs: operand(out = o, k) = src[k][coff + o] for k < H, src2[k - H][coff + o] beyond
+        const float* src[2] = {wn, wz};
+        const float* src2[2] = {wn, wr};
+        float* dst[2] = {Pnh + g * n1, Pzrh + g * n2};
+        const int K[2] = {H, 2 * H};
+        for (int k = 0; k < 2; ++k) {
+            const int y = g * 2 + k;
             jobs.src[y] = src[k];
             jobs.src2[y] = src2[k];
             jobs.dst[y] = dst[k];
-            jobs.coff[y] = coff[k];
+            jobs.coff[y] = H;
             jobs.K[y] = K[k];
             jobs.transposed[y] = 1;
         }
     }
-    return rnn_launch_pack(jobs, 4 * G, ld, H, 2 * H, (hipStream_t)stream);
+    return rnn_launch_pack(jobs, 2 * G, ld, H, 2 * H, (hipStream_t)stream);
 }
 
-extern "C" int dpk_gru_forward(const float* const* xp, const float* const* h0, const float* Pz, const float* Pr,
-                               const float* Pn, const float* const* bias, float* out, float* Z, float* R, float* N,
-                               float* Azr, float* An, int B, int T, int H, int G, void* stream) {
-    if (!xp || !Pz || !Pr || !Pn || !bias || !out || !Z || !R || !N || !Azr || !An) return DPK_EINVAL;
+extern "C" int dpk_gru_forward(const float* const* xp, const float* const* xg, const float* const* h0,
+                               const float* Pz, const float* Pr, const float* Pn, float* out, float* Z, float* R,
+                               float* N, float* Azr, float* An, int B, int T, int H, int G, void* stream) {
+    if (!xp || !xg || !Pz || !Pr || !Pn || !out || !Z || !R || !N || !Azr || !An) return DPK_EINVAL;
     if (int rc = gru_check_shape(B, T, H, G)) return rc;
     const void* ptrs[] = {Pz, Pr, Pn, out, Z, R, N, Azr, An};
     for (const void* p : ptrs)
         if (!dpk_aligned16(p)) return DPK_EALIGN;
-    GPtrs xps{}, h0s{};
-    GPtrs3 bs{};
+    GPtrs xps{}, xgs{}, h0s{};
     for (int g = 0; g < G; ++g) {
-        if (!xp[g] || !bias[3 * g] || !bias[3 * g + 1] || !bias[3 * g + 2]) return DPK_EINVAL;
+        if (!xp[g] || !xg[g]) return DPK_EINVAL;
         xps.p[g] = xp[g];
+        xgs.p[g] = xg[g];
         h0s.p[g] = h0 ? h0[g] : nullptr;
-        for (int k = 0; k < 3; ++k) bs.p[3 * g + k] = bias[3 * g + k];
-        if (!dpk_aligned16(xps.p[g]) || !dpk_aligned16(h0s.p[g]) || !dpk_aligned16(bs.p[3 * g]) ||
-            !dpk_aligned16(bs.p[3 * g + 1]) || !dpk_aligned16(bs.p[3 * g + 2]))
-            return DPK_EALIGN;
+        if (!dpk_aligned16(xps.p[g]) || !dpk_aligned16(xgs.p[g]) || !dpk_aligned16(h0s.p[g])) return DPK_EALIGN;
     }
     const int tpw = gru_tpw(H);
-    const size_t lds = (size_t)2 * ((2 * H + 15) / 16) * 16 * GBT * sizeof(float);
-    if (lds > 150 * 1024) return DPK_ERANGE;
+    const size_t lds = (size_t)2 * ((H + 15) / 16) * 16 * GBT * sizeof(float);
     dim3 grid((unsigned)((B + GBT - 1) / GBT), (unsigned)G);
     hipStream_t s = (hipStream_t)stream;
 #define DPK_GRU_F(TPW)                                                                                              \
-    do {                                                                                                            \
-        if (lds > 64 * 1024) {                                                                                      \
-            hipError_t e_ = hipFuncSetAttribute((const void*)gru_fwd_kernel<TPW, (TPW < 4)>,                        \
-                                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);              \
-            if (e_ != hipSuccess) return (int)e_;                                                                   \
-        }                                                                                                           \
-        hipLaunchKernelGGL((gru_fwd_kernel<TPW, (TPW < 4)>), grid, dim3(GNW * 64), lds, s, xps, h0s,                \
-                           (const f32x4*)Pz, (const f32x4*)Pr, (const f32x4*)Pn, bs, out, Z, R, N, Azr, An, B, T,  \
-                           H);                                                                                      \
-    } while (0)
+    hipLaunchKernelGGL((gru_fwd_kernel<TPW, (TPW < 4)>), grid, dim3(GNW * 64), lds, s, xps, xgs, h0s,               \
+                       (const f32x4*)Pz, (const f32x4*)Pr, (const f32x4*)Pn, out, Z, R, N, Azr, An, B, T, H)
     if (tpw == 1) DPK_GRU_F(1);
     else if (tpw == 2) DPK_GRU_F(2);
     else DPK_GRU_F(4);
@@ -397,13 +417,11 @@ extern "C" int dpk_gru_forward(const float* const* xp, const float* const* h0, c
 }
 
 extern "C" int dpk_gru_backward(const float* const* dout, const float* const* dhT, const float* Z, const float* R,
-                                const float* N, const float* Azr, const float* Pnx, const float* Pnh,
-                                const float* Pzrx, const float* Pzrh, float* dxp, float* Gz, float* Gr, float* Gn,
+                                const float* N, const float* Azr, const float* Pnh, const float* Pzrh, float* G3,
                                 float* dh0, int B, int T, int H, int G, void* stream) {
-    if (!dout || !Z || !R || !N || !Azr || !Pnx || !Pnh || !Pzrx || !Pzrh || !dxp || !Gz || !Gr || !Gn)
-        return DPK_EINVAL;
+    if (!dout || !Z || !R || !N || !Azr || !Pnh || !Pzrh || !G3) return DPK_EINVAL;
     if (int rc = gru_check_shape(B, T, H, G)) return rc;
-    const void* ptrs[] = {Z, R, N, Azr, Pnx, Pnh, Pzrx, Pzrh, dxp, Gz, Gr, Gn, dh0};
+    const void* ptrs[] = {Z, R, N, Azr, Pnh, Pzrh, G3, dh0};
     for (const void* p : ptrs)
         if (p && !dpk_aligned16(p)) return DPK_EALIGN;
     GPtrs ds{}, hs{};
@@ -425,8 +443,7 @@ extern "C" int dpk_gru_backward(const float* const* dout, const float* const* dh
             if (e_ != hipSuccess) return (int)e_;                                                                   \
         }                                                                                                           \
         hipLaunchKernelGGL((gru_bwd_kernel<TPW, (TPW < 4)>), grid, dim3(GNW * 64), lds, s, ds, hs, Z, R, N, Azr,    \
-                           (const f32x4*)Pnx, (const f32x4*)Pnh, (const f32x4*)Pzrx, (const f32x4*)Pzrh, dxp, Gz,  \
-                           Gr, Gn, dh0, B, T, H);                                                                   \
+                           (const f32x4*)Pnh, (const f32x4*)Pzrh, G3, dh0, B, T, H);                                \
     } while (0)
     if (tpw == 1) DPK_GRU_B(1);
     else if (tpw == 2) DPK_GRU_B(2);

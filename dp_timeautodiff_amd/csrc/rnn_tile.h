@@ -183,6 +183,79 @@ __device__ __forceinline__ void mfma_tile2(f32x4& a0, f32x4& a1, const f32x4* __
     }
 }
 
+// one output tile, K split over two independent accumulator chains (even / odd K groups), summed at the end: a single
+// chain issues a 16x16x4 MFMA every 44 cycles, two every 32 (tools/lab/mfma_rate.hip)
+template <int GPF>
+__device__ __forceinline__ void mfma_tile_ks(f32x4& acc, const f32x4* __restrict__ wp, const float* __restrict__ sB,
+                                             int KG, int lane) {
+    const int q = lane >> 4, j = lane & 15;
+    const float* p = sB + q * GBT + j;
+    const f32x4* pw = wp + lane;
+    const int KP = KG >> 1;  // pairs of K groups
+    f32x4 a1 = {0.f, 0.f, 0.f, 0.f};
+    if (KP > 0) {
+        f32x4 w0[GPF], w1[GPF];
+#pragma unroll
+        for (int s = 0; s < GPF; ++s) {
+            const int o = (s < KP ? s : KP - 1) * 128;
+            w0[s] = pw[o];
+            w1[s] = pw[o + 64];
+        }
+        BFrag b0 = ld_bfrag(p), b1 = ld_bfrag(p + 16 * GBT);
+        int kp = 0;
+        for (; kp + 2 * GPF <= KP; kp += GPF) {
+#pragma unroll
+            for (int s = 0; s < GPF; ++s) {
+                p += 32 * GBT;
+                const BFrag n0 = ld_bfrag(p), n1 = ld_bfrag(p + 16 * GBT);
+                __builtin_amdgcn_sched_barrier(0);
+                DPK_MFMA4(acc, w0[s], b0.b0, b0.b1, b0.b2, b0.b3);
+                w0[s] = pw[(kp + s + GPF) * 128];
+                DPK_MFMA4(a1, w1[s], b1.b0, b1.b1, b1.b2, b1.b3);
+                w1[s] = pw[(kp + s + GPF) * 128 + 64];
+                __builtin_amdgcn_sched_barrier(0);
+                b0 = n0;
+                b1 = n1;
+            }
+        }
+        const int rem = KP - kp;
+#pragma unroll
+        for (int s = 0; s < GPF; ++s) {
+            if (s < rem) {
+                const float* pn = p + (s + 1 < rem ? 32 * GBT : 0);
+                const BFrag n0 = ld_bfrag(pn), n1 = ld_bfrag(pn + 16 * GBT);
+                DPK_MFMA4(acc, w0[s], b0.b0, b0.b1, b0.b2, b0.b3);
+                DPK_MFMA4(a1, w1[s], b1.b0, b1.b1, b1.b2, b1.b3);
+                if (s + GPF < rem) {
+                    w0[s] = pw[(kp + s + GPF) * 128];
+                    w1[s] = pw[(kp + s + GPF) * 128 + 64];
+                }
+                p = pn;
+                b0 = n0;
+                b1 = n1;
+            }
+        }
+#pragma unroll
+        for (int s = 0; s < GPF; ++s) {
+            if (s + GPF < rem) {
+                const float* pn = p + (s + GPF + 1 < rem ? 32 * GBT : 0);
+                const BFrag n0 = ld_bfrag(pn), n1 = ld_bfrag(pn + 16 * GBT);
+                DPK_MFMA4(acc, w0[s], b0.b0, b0.b1, b0.b2, b0.b3);
+                DPK_MFMA4(a1, w1[s], b1.b0, b1.b1, b1.b2, b1.b3);
+                p = pn;
+                b0 = n0;
+                b1 = n1;
+            }
+        }
+    }
+    if (KG & 1) {  // odd last group
+        const f32x4 w = pw[(KG - 1) * 64];
+        const BFrag b = ld_bfrag(sB + (KG - 1) * 16 * GBT + q * GBT + j);
+        DPK_MFMA4(a1, w, b.b0, b.b1, b.b2, b.b3);
+    }
+    acc += a1;
+}
+
 __device__ __forceinline__ f32x4 ld4(const float* p) { return *reinterpret_cast<const f32x4*>(p); }
 __device__ __forceinline__ void st4(float* p, f32x4 v) { *reinterpret_cast<f32x4*>(p) = v; }
 

@@ -41,23 +41,32 @@ class _Recurrence(torch.autograd.Function):
         has_h0 = per[0][1] is not None
         h0s = [p[1].contiguous() for p in per] if has_h0 else None
         weights = [p[2 + 2 * k].contiguous() for p in per for k in range(3)]
-        biases = [p[3 + 2 * k].contiguous() for p in per for k in range(3)]
+        # input halves of all three gates for all T steps: one GEMM per GRU (the recurrence only runs the hidden halves)
+        wx = torch.cat([w[:, :H] for w in weights], 0)                      # [G*3H, H]: update | reset | new per GRU
+        bx = torch.cat([p[3 + 2 * k] for p in per for k in range(3)], 0)    # [G*3H]
+        xgs = [torch.addmm(bx[3 * H * g:3 * H * (g + 1)], xps[g].view(-1, H), wx[3 * H * g:3 * H * (g + 1)].t())
+               .view(*xps[g].shape[:2], 3 * H) for g in range(G)]
         packs = _native.gru_pack_forward(weights, H)
-        out, Z, R, N, Azr, An = _native.gru_forward(xps, h0s, *packs, biases)
+        out, Z, R, N, Azr, An = _native.gru_forward(xps, xgs, h0s, *packs)
         ctx.owners, ctx.feed, ctx.has_h0 = owners, feed, has_h0
-        ctx.save_for_backward(Z, R, N, Azr, An, *weights)
+        ctx.save_for_backward(Z, R, N, Azr, An, wx, *weights)
         return tuple(out[g] for g in range(G))
 
     @staticmethod
     def backward(ctx, *douts):
-        Z, R, N, Azr, An, *weights = ctx.saved_tensors
+        Z, R, N, Azr, An, wx, *weights = ctx.saved_tensors
         G, B, T, H = Z.shape
         owners = ctx.owners
         packs = _native.gru_pack_backward(weights, H)
         need = ctx.needs_input_grad[2:]
         want_dh0 = ctx.has_h0 and any(need[8 * g + 1] for g in range(G))
         douts = [None if d is None else d.contiguous() for d in douts]
-        dxp, Gz, Gr, Gn, dh0 = _native.gru_backward(douts, None, Z, R, N, Azr, *packs, want_dh0)
+        G3, dh0 = _native.gru_backward(douts, None, Z, R, N, Azr, *packs, want_dh0)
+        Gz, Gr, Gn = G3[..., :H], G3[..., H:2 * H], G3[..., 2 * H:]  # column blocks: K1 reads them with ld_g = 3H
+        dxp = [None] * G
+        for g in range(G):
+            if need[8 * g]:  # dL/dxp: the input halves' transposed products, all T steps and all gates in one GEMM
+                dxp[g] = torch.mm(G3[g].view(-1, 3 * H), wx[3 * H * g:3 * H * (g + 1)]).view(B, T, H)
         grads = []
         if ctx.feed:  # per-sample gradients: K1 straight from the kernels' buffers
             jobs, hosts = [], set()

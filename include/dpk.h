@@ -72,13 +72,15 @@ int dpk_linear_grad_sample(const float* A, const float* G, float* GSw, float* GS
  * the sampler back to back, and six thin launches leave six tails.  A, G, GSw, GSb (nullable as a whole or per entry)
  * and slot0 are HOST arrays of n_jobs entries (device pointers / slot indices); every job writes its own
  * dpk_linear_slots(in,out) partials at slot0[j].  Results are identical to n_jobs dpk_linear_grad_sample calls.
+ * ld_g >= out is the row stride of every G[j] (the fused GRU backward writes the three gates' backprops side by side
+ * in one [B,T,3H] buffer so that dL/dx is a single GEMM: each gate's G is then a column block with ld_g = 3H).
  */
 #define DPK_K1_MAX_JOBS 8
 int dpk_linear_grad_sample_group(const float* const* A, const float* const* G, float* const* GSw,
                                  float* const* GSb, const int* slot0, int n_jobs,
                                  float* normsq_part, int64_t part_stride,
                                  int B, int T, int in_features, int out_features,
-                                 int64_t gs_stride, int ld_w, float g_scale, void* stream);
+                                 int64_t gs_stride, int ld_w, int ld_g, float g_scale, void* stream);
 
 /*
  * K3 — per-sample gradient of nn.Embedding.  Replaces Opacus' Embedding sampler
@@ -170,32 +172,37 @@ int dpk_philox_normal(float* out, int64_t n, uint64_t seed, uint64_t offset, flo
  * pointers (`const float* const*`, read during the call; the tensors may live anywhere); everything the kernels
  * WRITE, and the packed weights, are single buffers with a leading contiguous [G] dimension.
  *
- * Gate weights are nn.Linear(2H, H) weights ([H, 2H] row-major, row stride ld), given as W[3g+0..2] =
- * {update, reset, new} of GRU g and re-ordered into MFMA fragment order by the pack calls (one launch each):
- *   pack_forward : Pz, Pr, Pn          [G, dpk_gru_pack_floats(H, 2H)]
- *   pack_backward: Pnx, Pnh            [G, dpk_gru_pack_floats(H, H)]     W_new^T, input / hidden half
- *                  Pzrx, Pzrh          [G, dpk_gru_pack_floats(H, 2H)]    [W_update; W_reset]^T, input / hidden half
+ * Only the HIDDEN half of every gate is sequential.  The input half, W[:, :H] x_t + b for all T steps, is one
+ * ordinary GEMM the caller runs first (xg [B,T,3H], column blocks update | reset | new), and dL/dxp is one GEMM over
+ * all T steps afterwards (dxp = Gz W_u[:, :H] + Gr W_r[:, :H] + Gn W_n[:, :H]): that halves the MFMA work on the T-step
+ * latency chain and takes the x_t -> LDS transposes off it.
  *
- * forward:  xp[g] [B,T,H]; h0 NULL or h0[g] [B,H] (NULL entry = zeros); bias[3g+0..2] = {update, reset, new} biases.
+ * Gate weights are nn.Linear(2H, H) weights ([H, 2H] row-major, row stride ld), given as W[3g+0..2] =
+ * {update, reset, new} of GRU g; their hidden halves W[:, H:] are re-ordered into MFMA fragment order by the pack
+ * calls (one launch each):
+ *   pack_forward : Pz, Pr, Pn          [G, dpk_gru_pack_floats(H, H)]
+ *   pack_backward: Pnh                 [G, dpk_gru_pack_floats(H, H)]     W_new[:, H:]^T
+ *                  Pzrh                [G, dpk_gru_pack_floats(H, 2H)]    [W_update[:, H:]; W_reset[:, H:]]^T
+ *
+ * forward:  xp[g] [B,T,H] (copied through into Azr / An), xg[g] [B,T,3H] (biases included); h0 NULL or h0[g] [B,H]
+ *   (NULL entry = zeros).
  *   writes out = h_t, the gate activations Z, R, N ([G,B,T,H]) and the gates' stacked input activations
  *   Azr = [xp_t | h_{t-1}] (update, reset) and An = [xp_t | r_t*h_{t-1}] (new), both [G,B,T,2H] — exactly the `A`
  *   operand dpk_linear_grad_sample contracts with K = T.
  * backward: dout[g] [B,T,H] = dL/dout (NULL entry = zeros); dhT NULL or dhT[g] [B,H] added at t = T-1.
- *   writes dxp [G,B,T,H], the gates' pre-activation gradients Gz, Gr, Gn [G,B,T,H] (the `G` operands of
- *   dpk_linear_grad_sample) and, if non-NULL, dh0 [G,B,H].
+ *   writes the gates' pre-activation gradients side by side, G3 [G,B,T,3H] = [Gz | Gr | Gn] (= dL/dxg; each column
+ *   block is a `G` operand of dpk_linear_grad_sample_group with ld_g = 3H) and, if non-NULL, dh0 [G,B,H].
  */
 #define DPK_GRU_MAX_G 8
 int64_t dpk_gru_pack_floats(int O, int K);
 int dpk_gru_pack_forward(const float* const* W, int ld, float* Pz, float* Pr, float* Pn, int H, int G, void* stream);
-int dpk_gru_pack_backward(const float* const* W, int ld, float* Pnx, float* Pnh, float* Pzrx, float* Pzrh,
-                          int H, int G, void* stream);
-int dpk_gru_forward(const float* const* xp, const float* const* h0, const float* Pz, const float* Pr,
-                    const float* Pn, const float* const* bias, float* out, float* Z, float* R, float* N,
+int dpk_gru_pack_backward(const float* const* W, int ld, float* Pnh, float* Pzrh, int H, int G, void* stream);
+int dpk_gru_forward(const float* const* xp, const float* const* xg, const float* const* h0, const float* Pz,
+                    const float* Pr, const float* Pn, float* out, float* Z, float* R, float* N,
                     float* Azr, float* An, int B, int T, int H, int G, void* stream);
 int dpk_gru_backward(const float* const* dout, const float* const* dhT, const float* Z, const float* R,
-                     const float* N, const float* Azr, const float* Pnx, const float* Pnh,
-                     const float* Pzrx, const float* Pzrh, float* dxp, float* Gz, float* Gr, float* Gn,
-                     float* dh0, int B, int T, int H, int G, void* stream);
+                     const float* N, const float* Azr, const float* Pnh, const float* Pzrh,
+                     float* G3, float* dh0, int B, int T, int H, int G, void* stream);
 
 /*
  * K11 — on-device Poisson sampler.  Replaces the host side of Opacus' DPDataLoader /

@@ -162,6 +162,35 @@ def test_linear_grad_sample_group_equals_single_launches(nat, B, T, in_f, out_f,
     assert (outs[1][1][:, 0] == -1).all() and (outs[1][1][:, 1:] >= 0).all()
 
 
+@pytest.mark.parametrize("B,T,in_f,out_f", [(20, 24, 256, 128), (6, 24, 16, 40), (5, 60, 300, 136)])
+def test_linear_grad_sample_reads_column_blocks_of_a_wider_backprop_buffer(nat, B, T, in_f, out_f):
+    """G operands that are column blocks of one [B,T,3*out] buffer (ld_g = 3*out, as the fused GRU backward writes
+    them) give bit-identical results to contiguous copies."""
+    g = torch.Generator().manual_seed(7)
+    A = torch.randn(B, T, in_f, generator=g).cuda()
+    G3 = torch.randn(B, T, 3 * out_f, generator=g).cuda()
+    nw = in_f * out_f
+    slots = nat.linear_slots(in_f, out_f)
+    outs = []
+    for strided in (False, True):
+        base, off = _arena(B, 3 * (nw + out_f))
+        part = torch.zeros(B, 3 * slots, device="cuda")
+        jobs = []
+        for k in range(3):
+            Gk = G3[..., k * out_f:(k + 1) * out_f]
+            o = off + k * (nw + out_f)
+            jobs.append((A, Gk if strided else Gk.contiguous(), nat.FlatView(base, o, nw),
+                         nat.FlatView(base, o + nw, out_f), k * slots))
+        if strided:
+            nat.linear_grad_sample_group(jobs[:2], part, float(B))
+            nat.linear_grad_sample(*jobs[2][:4], part, jobs[2][4], float(B))  # single-call form of a strided G
+        else:
+            for A_, G_, vw, vb, s0 in jobs:
+                nat.linear_grad_sample(A_, G_, vw, vb, part, s0, float(B))
+        outs.append((base.cpu(), part.cpu()))
+    assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
+
+
 @pytest.mark.parametrize("case", ["vae_small_mixed.npz", "vae_small_nums.npz", "denoiser_small.npz"])
 def test_stacked_calls_match_reference_autograd(nat, golden, case):
     """T calls of one Linear stacked into one K=T contraction == the reference's per-sample grads."""
