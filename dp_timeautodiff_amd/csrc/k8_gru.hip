@@ -43,11 +43,42 @@ __device__ __forceinline__ void phase_tiles(f32x4 (&acc)[TPW], const f32x4* __re
     }
 }
 
+// Register-resident weights (H <= 128: a wave's whole slice of the three gates is 24 x 16 bytes per lane): loaded once
+// before the T-step loop, so no weight leaves L2 inside the latency chain and no phase starts by waiting for one.
+template <int R>
+__device__ __forceinline__ void res_load(f32x4 (&w)[R], const f32x4* __restrict__ P, bool live, int lane) {
+#pragma unroll
+    for (int kg = 0; kg < R; ++kg) w[kg] = live ? P[kg * 64 + lane] : f32x4{0.f, 0.f, 0.f, 0.f};
+}
+template <int R>
+__device__ __forceinline__ void res_tile2(f32x4& a0, f32x4& a1, const f32x4 (&w0)[R], const f32x4 (&w1)[R],
+                                          const float* __restrict__ sB, int lane) {
+    const float* p = sB + (lane >> 4) * GBT + (lane & 15);
+#pragma unroll
+    for (int kg = 0; kg < R; ++kg) {
+        const BFrag b = ld_bfrag(p + kg * 16 * GBT);
+        DPK_MFMA4(a0, w0[kg], b.b0, b.b1, b.b2, b.b3);
+        DPK_MFMA4(a1, w1[kg], b.b0, b.b1, b.b2, b.b3);
+    }
+}
+template <int R>
+__device__ __forceinline__ void res_tile_ks(f32x4& acc, const f32x4 (&w)[R], const float* __restrict__ sB, int lane) {
+    const float* p = sB + (lane >> 4) * GBT + (lane & 15);
+    f32x4 a1 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int kg = 0; kg < R; kg += 2) {
+        const BFrag b0 = ld_bfrag(p + kg * 16 * GBT), b1 = ld_bfrag(p + (kg + 1) * 16 * GBT);
+        DPK_MFMA4(acc, w[kg], b0.b0, b0.b1, b0.b2, b0.b3);
+        DPK_MFMA4(a1, w[kg + 1], b1.b0, b1.b1, b1.b2, b1.b3);
+    }
+    acc += a1;
+}
+
 // Forward.  The x half of every gate (W[:, :H] x_t + b, all T steps) is ONE ordinary GEMM outside the kernel
 // (xg [B,T,3H], column blocks z | r | n): only the h half (K = H) is sequential, which halves the MFMA work on the
 // T-step latency chain and removes the per-step x_t -> LDS transpose and its barrier.  x_t itself only passes through
 // (global -> global) into the x halves of the gates' stacked activations Azr / An that K1 contracts.
-template <int TPW, bool PRE>
+template <int TPW, bool PRE, int RKG>  // RKG > 0: KG == RKG K groups of weights live in registers (TPW == 1)
 __global__ void __launch_bounds__(GNW * 64) gru_fwd_kernel(GPtrs xps, GPtrs xgs, GPtrs h0s, const f32x4* __restrict__ Pz,
                                                            const f32x4* __restrict__ Pr, const f32x4* __restrict__ Pn,
                                                            float* __restrict__ out, float* __restrict__ Z,
@@ -131,6 +162,13 @@ __global__ void __launch_bounds__(GNW * 64) gru_fwd_kernel(GPtrs xps, GPtrs xgs,
             }
         }
     };
+    constexpr int RW = RKG > 0 ? RKG : 1;
+    f32x4 wz[RW], wr[RW], wn[RW];
+    if constexpr (RKG > 0) {
+        res_load<RW>(wz, Pz + (int64_t)wave * tile_stride, wave < NT, lane);
+        res_load<RW>(wr, Pr + (int64_t)wave * tile_stride, wave < NT, lane);
+        res_load<RW>(wn, Pn + (int64_t)wave * tile_stride, wave < NT, lane);
+    }
     load_g(0);
     lds_barrier();
 
@@ -140,11 +178,15 @@ __global__ void __launch_bounds__(GNW * 64) gru_fwd_kernel(GPtrs xps, GPtrs xgs,
 #pragma unroll
         for (int i = 0; i < TPW; ++i) { az[i] = gz[i]; ar[i] = gr[i]; }
         load_x(t);
+        if constexpr (RKG > 0) {
+            res_tile2<RW>(az[0], ar[0], wz, wr, bufA, lane);
+        } else {
 #pragma unroll
-        for (int i = 0; i < TPW; ++i) {
-            const int ot = wave + GNW * i;
-            if (ot < NT) mfma_tile2<GPF>(az[i], ar[i], Pz + (int64_t)ot * tile_stride, Pr + (int64_t)ot * tile_stride, bufA,
-                                         KG, lane);
+            for (int i = 0; i < TPW; ++i) {
+                const int ot = wave + GNW * i;
+                if (ot < NT) mfma_tile2<GPF>(az[i], ar[i], Pz + (int64_t)ot * tile_stride, Pr + (int64_t)ot * tile_stride,
+                                             bufA, KG, lane);
+            }
         }
         store_x(t);
         f32x4 an[TPW];
@@ -173,7 +215,8 @@ __global__ void __launch_bounds__(GNW * 64) gru_fwd_kernel(GPtrs xps, GPtrs xgs,
         if (PRE && t + 1 < T) { load_g(t + 1); }  // gn of this step already moved to an[]
         lds_barrier();
         // ---- phase 2: n, h' ---------------------------------------------------------------------------------
-        phase_tiles<TPW, GPF>(an, Pn, tile_stride, bufB, KG, NT, wave, lane);
+        if constexpr (RKG > 0) res_tile_ks<RW>(an[0], wn, bufB, lane);
+        else phase_tiles<TPW, GPF>(an, Pn, tile_stride, bufB, KG, NT, wave, lane);
 #pragma unroll
         for (int i = 0; i < TPW; ++i) {
             const int ot = wave + GNW * i;
@@ -200,7 +243,7 @@ __global__ void __launch_bounds__(GNW * 64) gru_fwd_kernel(GPtrs xps, GPtrs xgs,
 // Backward.  Only the h halves of the transposed products are sequential (d(r*h) = Wn[:, H:]^T dn_pre, then
 // dh += [Wz[:, H:]; Wr[:, H:]]^T [dz_pre | dr_pre]); the x halves (dL/dx_t) are one GEMM over all T steps outside,
 // fed by the G_z | G_r | G_n rows (G3 [B,T,3H]) this kernel writes anyway for K1 (each gate a column block, ld_g = 3H).
-template <int TPW, bool PRE>
+template <int TPW, bool PRE, int RKG>
 __global__ void __launch_bounds__(GNW * 64) gru_bwd_kernel(GPtrs douts, GPtrs dhTs, const float* __restrict__ Z,
                                                            const float* __restrict__ R, const float* __restrict__ N,
                                                            const float* __restrict__ Azr, const f32x4* __restrict__ Pnh,
@@ -256,6 +299,12 @@ __global__ void __launch_bounds__(GNW * 64) gru_bwd_kernel(GPtrs douts, GPtrs dh
         dhc[i] = zero4;
         if (wave + GNW * i < NT && o < H && bvalid && dhT) dhc[i] = ld4(dhT + (int64_t)b * H + o);
     }
+    constexpr int RW = RKG > 0 ? RKG : 1;
+    f32x4 wnh[RW], wzrh[2 * RW];
+    if constexpr (RKG > 0) {
+        res_load<RW>(wnh, Pnh + (int64_t)wave * KGn * 64, wave < NT, lane);
+        res_load<2 * RW>(wzrh, Pzrh + (int64_t)wave * KGzr * 64, wave < NT, lane);
+    }
     if (PRE) load_step(T - 1);
 
     for (int t = T - 1; t >= 0; --t) {
@@ -288,7 +337,8 @@ __global__ void __launch_bounds__(GNW * 64) gru_bwd_kernel(GPtrs douts, GPtrs dh
         f32x4 ah[TPW];
 #pragma unroll
         for (int i = 0; i < TPW; ++i) ah[i] = zero4;
-        phase_tiles<TPW, GPF>(ah, Pnh, (int64_t)KGn * 64, sDn, KGn, NT, wave, lane);
+        if constexpr (RKG > 0) res_tile_ks<RW>(ah[0], wnh, sDn, lane);
+        else phase_tiles<TPW, GPF>(ah, Pnh, (int64_t)KGn * 64, sDn, KGn, NT, wave, lane);
 #pragma unroll
         for (int i = 0; i < TPW; ++i) {
             const int ot = wave + GNW * i;
@@ -303,7 +353,8 @@ __global__ void __launch_bounds__(GNW * 64) gru_bwd_kernel(GPtrs douts, GPtrs dh
         }
         lds_barrier();
         // ---- GEMM2: dh += [Wz[:, H:]; Wr[:, H:]]^T [dz_pre | dr_pre] ---------------------------------------
-        phase_tiles<TPW, GPF>(dhc, Pzrh, (int64_t)KGzr * 64, sDzr, KGzr, NT, wave, lane);
+        if constexpr (RKG > 0) res_tile_ks<2 * RW>(dhc[0], wzrh, sDzr, lane);
+        else phase_tiles<TPW, GPF>(dhc, Pzrh, (int64_t)KGzr * 64, sDzr, KGzr, NT, wave, lane);
         lds_barrier();  // sDn / sDzr are rewritten by the next (earlier) time step
     }
     if (dh0) {
@@ -406,12 +457,16 @@ extern "C" int dpk_gru_forward(const float* const* xp, const float* const* xg, c
     const size_t lds = (size_t)2 * ((H + 15) / 16) * 16 * GBT * sizeof(float);
     dim3 grid((unsigned)((B + GBT - 1) / GBT), (unsigned)G);
     hipStream_t s = (hipStream_t)stream;
-#define DPK_GRU_F(TPW)                                                                                              \
-    hipLaunchKernelGGL((gru_fwd_kernel<TPW, (TPW < 4)>), grid, dim3(GNW * 64), lds, s, xps, xgs, h0s,               \
+#define DPK_GRU_F(TPW, RKG)                                                                                         \
+    hipLaunchKernelGGL((gru_fwd_kernel<TPW, (TPW < 4), RKG>), grid, dim3(GNW * 64), lds, s, xps, xgs, h0s,          \
                        (const f32x4*)Pz, (const f32x4*)Pr, (const f32x4*)Pn, out, Z, R, N, Azr, An, B, T, H)
-    if (tpw == 1) DPK_GRU_F(1);
-    else if (tpw == 2) DPK_GRU_F(2);
-    else DPK_GRU_F(4);
+    const int kg = (H + 15) / 16;
+    const bool res = H % 16 == 0;  // the backward's [dz | dr] operand must be exactly 2*kg K groups
+    if (tpw == 1 && kg == 8 && res) DPK_GRU_F(1, 8);        // H = 128: weights live in registers
+    else if (tpw == 1 && kg == 4 && res) DPK_GRU_F(1, 4);   // H = 64
+    else if (tpw == 1) DPK_GRU_F(1, 0);
+    else if (tpw == 2) DPK_GRU_F(2, 0);
+    else DPK_GRU_F(4, 0);
 #undef DPK_GRU_F
     return dpk_launch_status();
 }
@@ -435,19 +490,24 @@ extern "C" int dpk_gru_backward(const float* const* dout, const float* const* dh
     if (lds > 150 * 1024) return DPK_ERANGE;
     dim3 grid((unsigned)((B + GBT - 1) / GBT), (unsigned)G);
     hipStream_t s = (hipStream_t)stream;
-#define DPK_GRU_B(TPW)                                                                                              \
+#define DPK_GRU_B(TPW, RKG)                                                                                         \
     do {                                                                                                            \
         if (lds > 64 * 1024) {                                                                                      \
-            hipError_t e_ = hipFuncSetAttribute((const void*)gru_bwd_kernel<TPW, (TPW < 4)>,                        \
+            hipError_t e_ = hipFuncSetAttribute((const void*)gru_bwd_kernel<TPW, (TPW < 4), RKG>,                   \
                                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);              \
             if (e_ != hipSuccess) return (int)e_;                                                                   \
         }                                                                                                           \
-        hipLaunchKernelGGL((gru_bwd_kernel<TPW, (TPW < 4)>), grid, dim3(GNW * 64), lds, s, ds, hs, Z, R, N, Azr,    \
+        hipLaunchKernelGGL((gru_bwd_kernel<TPW, (TPW < 4), RKG>), grid, dim3(GNW * 64), lds, s, ds, hs, Z, R, N,    \
+                           Azr,                                                                                     \
                            (const f32x4*)Pnh, (const f32x4*)Pzrh, G3, dh0, B, T, H);                                \
     } while (0)
-    if (tpw == 1) DPK_GRU_B(1);
-    else if (tpw == 2) DPK_GRU_B(2);
-    else DPK_GRU_B(4);
+    const int kg = (H + 15) / 16;
+    const bool res = H % 16 == 0;
+    if (tpw == 1 && kg == 8 && res) DPK_GRU_B(1, 8);
+    else if (tpw == 1 && kg == 4 && res) DPK_GRU_B(1, 4);
+    else if (tpw == 1) DPK_GRU_B(1, 0);
+    else if (tpw == 2) DPK_GRU_B(2, 0);
+    else DPK_GRU_B(4, 0);
 #undef DPK_GRU_B
     return dpk_launch_status();
 }
