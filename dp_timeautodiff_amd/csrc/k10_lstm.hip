@@ -17,6 +17,11 @@
 
 namespace {
 
+#ifndef DPK_K10_WAVES
+#define DPK_K10_WAVES 8
+#endif
+constexpr int LNW = DPK_K10_WAVES;  // waves per workgroup (lab: 16 waves, one hidden tile each, ran the forward 7 % slower)
+
 // rows of width H = 250 start 8-byte aligned at best: gfx950 global accesses need dword alignment only, so a full
 // group of 4 is one 16-byte access whatever its address (H=250 ran 20-24 % slower with scalar pieces)
 typedef float f32x4u __attribute__((ext_vector_type(4), aligned(4)));
@@ -104,13 +109,13 @@ __device__ __forceinline__ void mfma_tile4(f32x4 (&a)[4], const f32x4* __restric
 }
 
 template <int TPW>
-__global__ void __launch_bounds__(GNW * 64) lstm_fwd_kernel(GPtrs xgs, GPtrs h0s, GPtrs c0s, GPtrs bhhs,
+__global__ void __launch_bounds__(LNW * 64) lstm_fwd_kernel(GPtrs xgs, GPtrs h0s, GPtrs c0s, GPtrs bhhs,
                                                             const f32x4* __restrict__ P, float* __restrict__ out,
                                                             float* __restrict__ gates, float* __restrict__ C,
                                                             float* __restrict__ Hprev, int reverse_mask, int B, int T,
                                                             int H) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    constexpr int NTH = GNW * 64;
+    constexpr int NTH = LNW * 64;
     const int KG = (H + 15) / 16, NT = KG;
     float* hT = smem;  // [KG*16][16]  h_{t-1}, k-major, zero padded
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -136,7 +141,7 @@ __global__ void __launch_bounds__(GNW * 64) lstm_fwd_kernel(GPtrs xgs, GPtrs h0s
     const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int i = 0; i < TPW; ++i) {
-        const int o = (wave + GNW * i) * 16 + q * 4;
+        const int o = (wave + LNW * i) * 16 + q * 4;
         const int nv = min(4, H - o);
         hreg[i] = creg[i] = zero4;
 #pragma unroll
@@ -150,7 +155,7 @@ __global__ void __launch_bounds__(GNW * 64) lstm_fwd_kernel(GPtrs xgs, GPtrs h0s
     auto load_x = [&](int t) {
 #pragma unroll
         for (int i = 0; i < TPW; ++i) {
-            const int o = (wave + GNW * i) * 16 + q * 4;
+            const int o = (wave + LNW * i) * 16 + q * 4;
             const int nv = min(4, H - o);
 #pragma unroll
             for (int g = 0; g < 4; ++g)
@@ -165,7 +170,7 @@ __global__ void __launch_bounds__(GNW * 64) lstm_fwd_kernel(GPtrs xgs, GPtrs h0s
         f32x4 hnew[TPW];
 #pragma unroll
         for (int i = 0; i < TPW; ++i) {
-            const int ot = wave + GNW * i;
+            const int ot = wave + LNW * i;
             const int o = ot * 16 + q * 4;
             const int nv = min(4, H - o);
             hnew[i] = zero4;
@@ -205,23 +210,23 @@ __global__ void __launch_bounds__(GNW * 64) lstm_fwd_kernel(GPtrs xgs, GPtrs h0s
         lds_barrier();  // every wave has finished reading h_{t-1}
 #pragma unroll
         for (int i = 0; i < TPW; ++i) {
-            const int o = (wave + GNW * i) * 16 + q * 4;
+            const int o = (wave + LNW * i) * 16 + q * 4;
             const int nv = min(4, H - o);
             hreg[i] = hnew[i];
-            if (wave + GNW * i < NT && nv > 0) lds_colv(hT, o, j, hnew[i], nv);
+            if (wave + LNW * i < NT && nv > 0) lds_colv(hT, o, j, hnew[i], nv);
         }
         lds_barrier();
     }
 }
 
 template <int TPW>
-__global__ void __launch_bounds__(GNW * 64) lstm_bwd_kernel(GPtrs douts, GPtrs c0s, const float* __restrict__ gates,
+__global__ void __launch_bounds__(LNW * 64) lstm_bwd_kernel(GPtrs douts, GPtrs c0s, const float* __restrict__ gates,
                                                             const float* __restrict__ C,
                                                             const f32x4* __restrict__ Pt, float* __restrict__ dpre,
                                                             float* __restrict__ dh0, float* __restrict__ dc0,
                                                             int reverse_mask, int B, int T, int H) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    constexpr int NTH = GNW * 64;
+    constexpr int NTH = LNW * 64;
     const int NT = (H + 15) / 16;
     const int KG4 = (4 * H + 15) / 16;
     float* sD = smem;  // [KG4*16][16]  dpre_t, rows g*H + o, k-major, zero padded
@@ -254,7 +259,7 @@ __global__ void __launch_bounds__(GNW * 64) lstm_bwd_kernel(GPtrs douts, GPtrs c
         const int tp = rev ? t + 1 : t - 1;  // time index of the step processed before it
 #pragma unroll
         for (int i = 0; i < TPW; ++i) {
-            const int o = (wave + GNW * i) * 16 + q * 4;
+            const int o = (wave + LNW * i) * 16 + q * 4;
             const int nv = min(4, H - o);
             p_do[i] = p_c[i] = p_cp[i] = zero4;
 #pragma unroll
@@ -276,7 +281,7 @@ __global__ void __launch_bounds__(GNW * 64) lstm_bwd_kernel(GPtrs douts, GPtrs c
         const int t = rev ? T - 1 - s : s;
 #pragma unroll
         for (int i = 0; i < TPW; ++i) {
-            const int ot = wave + GNW * i;
+            const int ot = wave + LNW * i;
             const int o = ot * 16 + q * 4;
             const int nv = min(4, H - o);
             if (ot < NT && nv > 0) {
@@ -313,7 +318,7 @@ __global__ void __launch_bounds__(GNW * 64) lstm_bwd_kernel(GPtrs douts, GPtrs c
         } else {
 #pragma unroll
             for (int i = 0; i < TPW; i += 2) {
-                const int ot0 = wave + GNW * i, ot1 = wave + GNW * (i + 1);
+                const int ot0 = wave + LNW * i, ot1 = wave + LNW * (i + 1);
                 dhc[i] = dhc[i + 1] = zero4;
                 if (ot1 < NT)
                     mfma_tile2<4>(dhc[i], dhc[i + 1], Pt + (int64_t)ot0 * KG4 * 64, Pt + (int64_t)ot1 * KG4 * 64, sD, KG4,
@@ -326,9 +331,9 @@ __global__ void __launch_bounds__(GNW * 64) lstm_bwd_kernel(GPtrs douts, GPtrs c
     }
 #pragma unroll
     for (int i = 0; i < TPW; ++i) {
-        const int o = (wave + GNW * i) * 16 + q * 4;
+        const int o = (wave + LNW * i) * 16 + q * 4;
         const int nv = min(4, H - o);
-        if (wave + GNW * i < NT && nv > 0 && bvalid) {
+        if (wave + LNW * i < NT && nv > 0 && bvalid) {
             if (dh0) stv(dh0 + (int64_t)b * H + o, dhc[i], nv);
             if (dc0) stv(dc0 + (int64_t)b * H + o, dcc[i], nv);
         }
@@ -336,7 +341,7 @@ __global__ void __launch_bounds__(GNW * 64) lstm_bwd_kernel(GPtrs douts, GPtrs c
 }
 
 inline int lstm_tpw(int H) {
-    const int per = ((H + 15) / 16 + GNW - 1) / GNW;
+    const int per = ((H + 15) / 16 + LNW - 1) / LNW;
     return per <= 1 ? 1 : per <= 2 ? 2 : 0;
 }
 
@@ -408,10 +413,10 @@ extern "C" int dpk_lstm_forward(const float* const* xg, const float* const* h0, 
     dim3 grid((unsigned)((B + GBT - 1) / GBT), (unsigned)G);
     hipStream_t s = (hipStream_t)stream;
     if (lstm_tpw(H) == 1)
-        hipLaunchKernelGGL((lstm_fwd_kernel<1>), grid, dim3(GNW * 64), lds, s, xs, hs, cs, bs, (const f32x4*)P, out,
+        hipLaunchKernelGGL((lstm_fwd_kernel<1>), grid, dim3(LNW * 64), lds, s, xs, hs, cs, bs, (const f32x4*)P, out,
                            gates, C, Hprev, reverse_mask, B, T, H);
     else
-        hipLaunchKernelGGL((lstm_fwd_kernel<2>), grid, dim3(GNW * 64), lds, s, xs, hs, cs, bs, (const f32x4*)P, out,
+        hipLaunchKernelGGL((lstm_fwd_kernel<2>), grid, dim3(LNW * 64), lds, s, xs, hs, cs, bs, (const f32x4*)P, out,
                            gates, C, Hprev, reverse_mask, B, T, H);
     return dpk_launch_status();
 }
@@ -440,7 +445,7 @@ extern "C" int dpk_lstm_backward(const float* const* dout, const float* const* c
                                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);              \
             if (e_ != hipSuccess) return (int)e_;                                                                   \
         }                                                                                                           \
-        hipLaunchKernelGGL((lstm_bwd_kernel<TPW>), grid, dim3(GNW * 64), lds, s, ds, cs, gates, C,                  \
+        hipLaunchKernelGGL((lstm_bwd_kernel<TPW>), grid, dim3(LNW * 64), lds, s, ds, cs, gates, C,                  \
                            (const f32x4*)Pt, dpre, dh0, dc0, reverse_mask, B, T, H);                                \
     } while (0)
     if (lstm_tpw(H) == 1) DPK_LSTM_B(1);
