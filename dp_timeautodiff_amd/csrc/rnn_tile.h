@@ -62,6 +62,14 @@ __global__ void __launch_bounds__(256) gru_pack_kernel(PackJobs jobs, int ld, in
 // acc += W-tile x LDS operand, K in groups of 16 (4 MFMAs per 16-byte weight load).  A ring of GPF weight groups is
 // kept in flight (L2 latency ~ 3 groups of MFMA issue); the main loop is branch-free so that every ring slot stays in
 // fixed registers: a slot is refilled right after the MFMAs that consumed it have issued.
+// lab switch: -DDPK_LAB_W_L1 makes every weight load hit the same two K groups (L1-resident), which isolates the cost
+// of streaming the weights from L2 (results are then wrong, timing only)
+#ifdef DPK_LAB_W_L1
+#define DPK_WIDX(x) ((x) & 1)
+#else
+#define DPK_WIDX(x) (x)
+#endif
+
 #define DPK_MFMA4(ACC, W, B0, B1, B2, B3)                                   \
     ACC = __builtin_amdgcn_mfma_f32_16x16x4f32((W).x, B0, ACC, 0, 0, 0);    \
     ACC = __builtin_amdgcn_mfma_f32_16x16x4f32((W).y, B1, ACC, 0, 0, 0);    \
@@ -94,7 +102,7 @@ __device__ __forceinline__ void mfma_tile(f32x4& acc, const f32x4* __restrict__ 
             const BFrag bn = ld_bfrag(p);  // kg + s + 1 < KG here
             __builtin_amdgcn_sched_barrier(0);
             DPK_MFMA4(acc, w[s], bc.b0, bc.b1, bc.b2, bc.b3);
-            w[s] = pw[(kg + s + GPF) * 64];
+            w[s] = pw[DPK_WIDX(kg + s + GPF) * 64];
             __builtin_amdgcn_sched_barrier(0);
             bc = bn;
         }
@@ -147,9 +155,9 @@ __device__ __forceinline__ void mfma_tile2(f32x4& a0, f32x4& a1, const f32x4* __
             const BFrag bn = ld_bfrag(p);
             __builtin_amdgcn_sched_barrier(0);
             DPK_MFMA4(a0, w0[s], bc.b0, bc.b1, bc.b2, bc.b3);
-            w0[s] = pw0[(kg + s + GPF) * 64];
+            w0[s] = pw0[DPK_WIDX(kg + s + GPF) * 64];
             DPK_MFMA4(a1, w1[s], bc.b0, bc.b1, bc.b2, bc.b3);
-            w1[s] = pw1[(kg + s + GPF) * 64];
+            w1[s] = pw1[DPK_WIDX(kg + s + GPF) * 64];
             __builtin_amdgcn_sched_barrier(0);
             bc = bn;
         }
@@ -210,9 +218,9 @@ __device__ __forceinline__ void mfma_tile_ks(f32x4& acc, const f32x4* __restrict
                 const BFrag n0 = ld_bfrag(p), n1 = ld_bfrag(p + 16 * GBT);
                 __builtin_amdgcn_sched_barrier(0);
                 DPK_MFMA4(acc, w0[s], b0.b0, b0.b1, b0.b2, b0.b3);
-                w0[s] = pw[(kp + s + GPF) * 128];
+                w0[s] = pw[DPK_WIDX(kp + s + GPF) * 128];
                 DPK_MFMA4(a1, w1[s], b1.b0, b1.b1, b1.b2, b1.b3);
-                w1[s] = pw[(kp + s + GPF) * 128 + 64];
+                w1[s] = pw[DPK_WIDX(kp + s + GPF) * 128 + 64];
                 __builtin_amdgcn_sched_barrier(0);
                 b0 = n0;
                 b1 = n1;

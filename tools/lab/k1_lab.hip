@@ -554,41 +554,24 @@ __global__ void __launch_bounds__(NW * 64) k1_q(const float* __restrict__ A, con
             const float* pg = sG + lh * RS + mr * 32 + l31;
             const float* pa = sA + lh * CS + cg * (32 * NT) + l31;
             if constexpr (UNR > 1) {
-                // software-pipelined: the LDS reads of group g+1 are issued before the MFMAs of group g
-                constexpr int KU = UNR;
-                const int npairs = Tp >> 1;
-                const int ng = npairs / KU;
-                float ca[KU], cb[KU][NT], na[KU], nb[KU][NT];
-                if (ng > 0) {
+                // U k-pairs per trip: all LDS reads of the trip are issued before its MFMAs (one exposed LDS latency per
+                // U*NT MFMAs instead of per NT), no double buffering (U*(1+NT) extra registers only)
+                constexpr int U = UNR;
+                int kk = 0;
+                for (; kk + 2 * U <= Tp; kk += 2 * U) {
+                    float ca[U], cb[U][NT];
 #pragma unroll
-                    for (int i = 0; i < KU; ++i) {
-                        ca[i] = pg[(2 * i) * RS];
+                    for (int i = 0; i < U; ++i) {
+                        ca[i] = pg[(kk + 2 * i) * RS];
 #pragma unroll
-                        for (int j = 0; j < NT; ++j) cb[i][j] = pa[(2 * i) * CS + j * 32];
+                        for (int j = 0; j < NT; ++j) cb[i][j] = pa[(kk + 2 * i) * CS + j * 32];
                     }
-                }
-                for (int g = 0; g < ng; ++g) {
-                    const int kn = (g + 1 < ng ? g + 1 : g) * KU * 2;
 #pragma unroll
-                    for (int i = 0; i < KU; ++i) {
-                        na[i] = pg[(kn + 2 * i) * RS];
-#pragma unroll
-                        for (int j = 0; j < NT; ++j) nb[i][j] = pa[(kn + 2 * i) * CS + j * 32];
-                    }
-                    __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-                    for (int i = 0; i < KU; ++i)
+                    for (int i = 0; i < U; ++i)
 #pragma unroll
                         for (int j = 0; j < NT; ++j) acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(ca[i], cb[i][j], acc[j], 0, 0, 0);
-                    __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-                    for (int i = 0; i < KU; ++i) {
-                        ca[i] = na[i];
-#pragma unroll
-                        for (int j = 0; j < NT; ++j) cb[i][j] = nb[i][j];
-                    }
                 }
-                for (int kk = ng * KU * 2; kk < Tp; kk += 2) {
+                for (; kk < Tp; kk += 2) {
                     const float a = pg[kk * RS];
 #pragma unroll
                     for (int j = 0; j < NT; ++j) acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, pa[kk * CS + j * 32], acc[j], 0, 0, 0);
@@ -738,14 +721,14 @@ int main(int argc, char** argv) {
                     CK(hipFuncSetAttribute((const void*)kq, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 64)); \
                     CK(hipMemset(GS, 0, (size_t)s.B * stride * 4)); \
                     report(NAME, time_it([&] { hipLaunchKernelGGL(kq, dim3(256 * BPC), dim3(NW_ * 64), lds2, 0, A, G, GS, s.B, s.T, s.in_f, s.out_f, stride, 2.0f, tma, tna, part); })); } while (0)
-                QRUN2("Q 128x256 8w x2", 2, 8, 128, 256, 2, 3, 6);
-                QRUN2("Q 256x256 16w x1", 1, 16, 256, 256, 2, 3, 3);
-                QRUN2("Q 256x256 8w x1", 1, 8, 256, 256, 2, 6, 6);
-                QRUN2("Q 256x256 8w x2", 2, 8, 256, 256, 2, 6, 6);
-                QRUN2("Q 128x512 8w x2", 2, 8, 128, 512, 2, 3, 12);
-                QRUN2("Q 128x512 16w x1", 1, 16, 128, 512, 2, 2, 6);
-                QRUN2("Q 128x256 16w x1", 1, 16, 128, 256, 2, 2, 3);
-                QRUN2("Q 128x256 8w x2", 2, 8, 128, 256, 2, 3, 6);
+                QRUN("Q x2 u1", 2, 8, 128, 256, 2, 3, 6, 1, 0);
+                QRUN("Q x2 u2", 2, 8, 128, 256, 2, 3, 6, 2, 0);
+                QRUN("Q x2 u3", 2, 8, 128, 256, 2, 3, 6, 3, 0);
+                QRUN("Q x2 u4", 2, 8, 128, 256, 2, 3, 6, 4, 0);
+                QRUN("Q x2 u6", 2, 8, 128, 256, 2, 3, 6, 6, 0);
+                QRUN("Q x2 u1", 2, 8, 128, 256, 2, 3, 6, 1, 0);
+                QRUN("Q x2 u4 mfma-only", 2, 8, 128, 256, 2, 3, 6, 4, 14);
+                QRUN("Q x2 u1 mfma-only", 2, 8, 128, 256, 2, 3, 6, 1, 14);
                 check("Q");
             }
         }
