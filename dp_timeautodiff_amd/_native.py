@@ -50,7 +50,7 @@ EXPORTS = {
     "dpk_lstm_pack_forward": (c_int, [c_void_p, c_void_p, c_int, c_int, c_void_p]),
     "dpk_lstm_pack_backward": (c_int, [c_void_p, c_void_p, c_int, c_int, c_void_p]),
     "dpk_lstm_forward": (c_int, [c_void_p] * 9 + [c_int] * 5 + [c_void_p]),
-    "dpk_lstm_backward": (c_int, [c_void_p] * 8 + [c_int] * 5 + [c_void_p]),
+    "dpk_lstm_backward": (c_int, [c_void_p] * 8 + [c_int] * 6 + [c_void_p]),
     "dpk_gru_pack_floats": (c_int64, [c_int, c_int]),
     "dpk_gru_pack_forward": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p]),
     "dpk_gru_pack_backward": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_int, c_int, c_void_p]),
@@ -454,7 +454,7 @@ def lstm_pack_backward(whh, H: int):
 
 def lstm_forward(xgs, h0s, c0s, bhhs, P, reverse_mask: int):
     """xgs: G tensors [B,T,4H]; h0s/c0s: None or G tensors [B,H]; bhhs: None or G tensors [4H].
-    Returns out, gates [G,B,T,4H], C, Hprev ([G,B,T,H] unless noted)."""
+    Returns out [B,T,G*H] (recurrence g in column block g), gates [G,B,T,4H], C, Hprev [G,B,T,H]."""
     G = len(xgs)
     _req(xgs[0], "xg[0]")
     if G == 0 or G > GRU_MAX_G or xgs[0].dim() != 3 or xgs[0].shape[2] % 4:
@@ -471,7 +471,8 @@ def lstm_forward(xgs, h0s, c0s, bhhs, P, reverse_mask: int):
     if tuple(P.shape) != (G, 4, gru_pack_floats(H, H)) or not P.is_contiguous():
         raise DpkError("lstm_forward: P is not [G, 4, packed(H,H)]")
     dev = xgs[0].device
-    out, C, Hprev = (torch.empty(G, B, T, H, device=dev, dtype=torch.float32) for _ in range(3))
+    C, Hprev = (torch.empty(G, B, T, H, device=dev, dtype=torch.float32) for _ in range(2))
+    out = torch.empty(B, T, G * H, device=dev, dtype=torch.float32)
     gates = torch.empty(G, B, T, 4 * H, device=dev, dtype=torch.float32)
     rc = load().dpk_lstm_forward(xa, ha, ca, ba, _ptr(P), _ptr(out), _ptr(gates), _ptr(C), _ptr(Hprev),
                                  int(reverse_mask), B, T, H, G, _stream())
@@ -480,7 +481,8 @@ def lstm_forward(xgs, h0s, c0s, bhhs, P, reverse_mask: int):
 
 
 def lstm_backward(douts, c0s, gates, C, Pt, reverse_mask: int, want_d0: bool):
-    """Returns dpre [G,B,T,4H] and (dh0, dc0) [G,B,H] or (None, None)."""
+    """douts: G tensors [B,T,H] (None = zeros), all dense or all column blocks of one [B,T,W] gradient buffer.
+    Returns dpre [G,B,T,4H] and (dh0, dc0) [G,B,H] or (None, None)."""
     _req(C, "C"); _req(gates, "gates"); _req(Pt, "Pt")
     if C.dim() != 4 or not C.is_contiguous():
         raise DpkError("lstm_backward: C must be contiguous [G,B,T,H]")
@@ -491,13 +493,21 @@ def lstm_backward(douts, c0s, gates, C, Pt, reverse_mask: int, want_d0: bool):
         raise DpkError("lstm_backward: Pt has the wrong packed size")
     if len(douts) != G or (c0s is not None and len(c0s) != G):
         raise DpkError("lstm_backward: inconsistent number of recurrences")
-    da = _ptr_array(douts, "dout", (B, T, H), allow_none=True)
+    lds = {_rows_ld(d) for d in douts if d is not None}
+    if None in lds or len(lds) > 1 or any(d is not None and tuple(d.shape) != (B, T, H) for d in douts):
+        raise DpkError("lstm_backward: dout entries must be [B,T,H] rows of one common stride")
+    ld_dout = lds.pop() if lds else H
+    da = (c_void_p * G)()
+    for i, d in enumerate(douts):
+        if d is not None:
+            _req(d, f"dout[{i}]")
+            da[i] = d.data_ptr()
     ca = None if c0s is None else _ptr_array(c0s, "c0", (B, H))
     dpre = torch.empty_like(gates)
     dh0 = torch.empty(G, B, H, device=C.device, dtype=torch.float32) if want_d0 else None
     dc0 = torch.empty(G, B, H, device=C.device, dtype=torch.float32) if want_d0 else None
     rc = load().dpk_lstm_backward(da, ca, _ptr(gates), _ptr(C), _ptr(Pt), _ptr(dpre), _ptr(dh0), _ptr(dc0),
-                                  int(reverse_mask), B, T, H, G, _stream())
+                                  int(reverse_mask), B, T, H, G, int(ld_dout), _stream())
     _check(rc, "dpk_lstm_backward")
     return dpre, dh0, dc0
 

@@ -123,6 +123,7 @@ __global__ void __launch_bounds__(LNW * 64) lstm_fwd_kernel(GPtrs xgs, GPtrs h0s
     const int b = blockIdx.x * GBT + j;
     const bool bvalid = b < B;
     const int gi = blockIdx.y;
+    const int ld_out = (int)gridDim.y * H;
     const bool rev = (reverse_mask >> gi) & 1;
     const float* __restrict__ xg = xgs.p[gi];
     const float* __restrict__ h0 = h0s.p[gi];
@@ -131,7 +132,7 @@ __global__ void __launch_bounds__(LNW * 64) lstm_fwd_kernel(GPtrs xgs, GPtrs h0s
     const int64_t gate_stride = (int64_t)NT * KG * 64;
     {
         const int64_t g = gi, gx = g * B * T * H;
-        out += gx; C += gx; Hprev += gx; gates += 4 * gx;
+        out += g * H; C += gx; Hprev += gx; gates += 4 * gx;  // out is [B,T,G*H]: this recurrence's column block
         P += g * 4 * gate_stride;
     }
     for (int i = threadIdx.x; i < KG * 16 * GBT; i += NTH) smem[i] = 0.f;
@@ -202,7 +203,7 @@ __global__ void __launch_bounds__(LNW * 64) lstm_fwd_kernel(GPtrs xgs, GPtrs h0s
                         stv(gates + r * 4 * H + 3 * H + o, og, nv);
                         stv(C + r * H + o, c, nv);
                         stv(Hprev + r * H + o, hreg[i], nv);
-                        stv(out + r * H + o, hnew[i], nv);
+                        stv(out + r * ld_out + o, hnew[i], nv);
                     }
                 }
             }
@@ -224,7 +225,7 @@ __global__ void __launch_bounds__(LNW * 64) lstm_bwd_kernel(GPtrs douts, GPtrs c
                                                             const float* __restrict__ C,
                                                             const f32x4* __restrict__ Pt, float* __restrict__ dpre,
                                                             float* __restrict__ dh0, float* __restrict__ dc0,
-                                                            int reverse_mask, int B, int T, int H) {
+                                                            int reverse_mask, int B, int T, int H, int ld_dout) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     constexpr int NTH = LNW * 64;
     const int NT = (H + 15) / 16;
@@ -266,7 +267,7 @@ __global__ void __launch_bounds__(LNW * 64) lstm_bwd_kernel(GPtrs douts, GPtrs c
             for (int g = 0; g < 4; ++g) p_g[i][g] = zero4;
             if (nv > 0 && bvalid) {
                 const int64_t r = (int64_t)b * T + t;
-                if (dout) p_do[i] = ldv(dout + r * H + o, nv);
+                if (dout) p_do[i] = ldv(dout + r * ld_dout + o, nv);
 #pragma unroll
                 for (int g = 0; g < 4; ++g) p_g[i][g] = ldv(gates + r * 4 * H + g * H + o, nv);
                 p_c[i] = ldv(C + r * H + o, nv);
@@ -423,8 +424,8 @@ extern "C" int dpk_lstm_forward(const float* const* xg, const float* const* h0, 
 
 extern "C" int dpk_lstm_backward(const float* const* dout, const float* const* c0, const float* gates,
                                  const float* C, const float* Pt, float* dpre, float* dh0, float* dc0,
-                                 int reverse_mask, int B, int T, int H, int G, void* stream) {
-    if (!dout || !gates || !C || !Pt || !dpre) return DPK_EINVAL;
+                                 int reverse_mask, int B, int T, int H, int G, int ld_dout, void* stream) {
+    if (!dout || !gates || !C || !Pt || !dpre || ld_dout < H) return DPK_EINVAL;
     if (int rc = lstm_check(B, T, H, G)) return rc;
     const void* ptrs[] = {gates, C, Pt, dpre, dh0, dc0};
     for (const void* p : ptrs)
@@ -446,7 +447,7 @@ extern "C" int dpk_lstm_backward(const float* const* dout, const float* const* c
             if (e_ != hipSuccess) return (int)e_;                                                                   \
         }                                                                                                           \
         hipLaunchKernelGGL((lstm_bwd_kernel<TPW>), grid, dim3(LNW * 64), lds, s, ds, cs, gates, C,                  \
-                           (const f32x4*)Pt, dpre, dh0, dc0, reverse_mask, B, T, H);                                \
+                           (const f32x4*)Pt, dpre, dh0, dc0, reverse_mask, B, T, H, ld_dout);                       \
     } while (0)
     if (lstm_tpw(H) == 1) DPK_LSTM_B(1);
     else DPK_LSTM_B(2);

@@ -187,7 +187,8 @@ class DPRNNBase(nn.Module):
 class _LSTMRecurrence(torch.autograd.Function):
     """The recurrences of one DPLSTM layer (one per direction) in one K10 launch each way.
     Tensor arguments per direction d: xg_d [B,T,4H] (= ih_d(x), bias_ih included), h0_d, c0_d ([B,H] or None for
-    all), Whh_d [4H,H], bhh_d ([4H] or None).  Returns out_d [B,T,H] per direction, then c_n per direction."""
+    all), Whh_d [4H,H], bhh_d ([4H] or None).  Returns out [B,T,G*H] (the directions' outputs already concatenated:
+    the kernel writes direction d into column block d), then c_n per direction."""
 
     @staticmethod
     def forward(ctx, cells, feed, reverse_mask, *args):
@@ -206,10 +207,10 @@ class _LSTMRecurrence(torch.autograd.Function):
         ctx.cells, ctx.feed, ctx.reverse_mask, ctx.has_state = cells, feed, reverse_mask, has_state
         ctx.has_bias = bhhs is not None
         ctx.save_for_backward(gates, C, Hprev, *whh, *(c0s or []))
-        T = out.shape[2]
+        T = out.shape[1]
         c_n = tuple(C[g, :, 0 if (reverse_mask >> g) & 1 else T - 1] for g in range(G))
         ctx.mark_non_differentiable(*c_n)
-        return tuple(out[g] for g in range(G)) + c_n
+        return (out,) + c_n
 
     @staticmethod
     def backward(ctx, *grads_out):
@@ -220,7 +221,10 @@ class _LSTMRecurrence(torch.autograd.Function):
         H = C.shape[-1]
         need = ctx.needs_input_grad[3:]
         want_d0 = ctx.has_state and any(need[5 * g + 1] or need[5 * g + 2] for g in range(G))
-        douts = [None if d is None else d.contiguous() for d in grads_out[:G]]
+        dcat = grads_out[0]
+        if dcat is not None and not dcat.is_contiguous():
+            dcat = dcat.contiguous()
+        douts = [None if dcat is None else dcat[..., g * H:(g + 1) * H] for g in range(G)]  # column blocks, ld = G*H
         Pt = _native.lstm_pack_backward(list(whh), H)
         dpre, dh0, dc0 = _native.lstm_backward(douts, list(c0s) if c0s else None, gates, C, Pt, ctx.reverse_mask,
                                                want_d0)
@@ -281,11 +285,11 @@ class DPLSTM(DPRNNBase):
                     w, bias = w.detach(), (None if bias is None else bias.detach())
                 args += [xg, None if h0 is None else h0[k], None if c0 is None else c0[k], w, bias]
             res = _LSTMRecurrence.apply(tuple(cells), feed, 2 if D == 2 else 0, *args)
-            outs, c_last = res[:D], res[D:]
+            inp, c_last = res[0], res[1:]  # [B,T,D*H]: both directions, concatenated by the kernel itself
+            Hh = self.hidden_size
             for d in range(D):
-                hn.append(outs[d][:, 0] if d == 1 else outs[d][:, T - 1])
+                hn.append(inp[:, 0, Hh:2 * Hh] if d == 1 else inp[:, T - 1, :Hh])
                 cn.append(c_last[d])
-            inp = outs[0] if D == 1 else torch.cat(outs, dim=2)
             if self.dropout_layer is not None and layer < L - 1:
                 inp = self.dropout_layer(inp)
         out = inp if self.batch_first else inp.transpose(0, 1)

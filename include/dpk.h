@@ -224,11 +224,13 @@ int dpk_poisson_sample(uint64_t seed, uint64_t offset, const uint64_t* offset_de
  * walk t = T-1..0.  The input projection is done outside for all steps at once: xg[g] = ih(x) [B,T,4H] (bias_ih
  * included); Whh[g] is the hh weight [4H,H] row-major, bhh[g] its bias [4H] (bhh NULL or NULL entry = none).
  *   pack_forward : P  [G, 4, dpk_gru_pack_floats(H, H)]      pack_backward: Pt [G, dpk_gru_pack_floats(H, 4H)]
- * forward writes out = h_t [G,B,T,H], the gate activations `gates` [G,B,T,4H], the cell state C [G,B,T,H] and
+ * forward writes out = h_t [B,T,G*H] (recurrence g in the column block [gH, (g+1)H): the concatenated output of a
+ *   bidirectional layer, no torch.cat), the gate activations `gates` [G,B,T,4H], the cell state C [G,B,T,H] and
  *   Hprev [G,B,T,H] = the hidden state each step consumed (the `A` operand of hh's per-sample gradient).
  *   h0 / c0: NULL or per-recurrence [B,H] (NULL entry = zeros).
  * backward writes dpre [G,B,T,4H] = dL/d(pre-activation) — both dL/dxg and the `G` operand of the ih and hh
- *   per-sample-gradient contractions — and, if non-NULL, dh0 / dc0 [G,B,H].  dout[g] [B,T,H] (NULL entry = zeros).
+ *   per-sample-gradient contractions — and, if non-NULL, dh0 / dc0 [G,B,H].  dout[g]: [B,T,H] rows of stride ld_dout
+ *   (H for a dense tensor, G*H for column block g of the concatenated output's gradient; NULL entry = zeros).
  * H <= 256, any H >= 1 (rows that are not 16-byte aligned are accessed in smaller pieces).
  */
 int dpk_lstm_pack_forward(const float* const* Whh, float* P, int H, int G, void* stream);
@@ -238,7 +240,7 @@ int dpk_lstm_forward(const float* const* xg, const float* const* h0, const float
                      float* Hprev, int reverse_mask, int B, int T, int H, int G, void* stream);
 int dpk_lstm_backward(const float* const* dout, const float* const* c0, const float* gates,
                       const float* C, const float* Pt, float* dpre, float* dh0, float* dc0,
-                      int reverse_mask, int B, int T, int H, int G, void* stream);
+                      int reverse_mask, int B, int T, int H, int G, int ld_dout, void* stream);
 
 /*
  * K9 — Adam with L2 weight decay on the arena-layout gradient.  Replaces
