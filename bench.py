@@ -48,25 +48,34 @@ def parse():
 
 
 class KernelTimer:
-    """Wraps one _native entry point with HIP events recorded on the launch stream."""
+    """Wraps _native entry points (one kernel family) with HIP events recorded on the launch stream.  Wrapped entry
+    points may call each other (the single-layer K1 call forwards strided operands to the grouped one): only the
+    outermost call is timed."""
 
-    def __init__(self, native, name):
-        self.native, self.name = native, name
-        self.orig = getattr(native, name)
+    def __init__(self, native, *names):
+        self.native, self.names = native, names
         self.events = []
         self.enabled = False
-        setattr(native, name, self)
+        self.depth = 0
+        for name in names:
+            setattr(native, name, self._wrap(getattr(native, name)))
 
-    def __call__(self, *a, **k):
-        if not self.enabled:
-            return self.orig(*a, **k)
-        e0 = torch.cuda.Event(enable_timing=True)
-        e1 = torch.cuda.Event(enable_timing=True)
-        e0.record()  # torch's current stream == the stream _native launches on
-        r = self.orig(*a, **k)
-        e1.record()
-        self.events.append((e0, e1))
-        return r
+    def _wrap(self, orig):
+        def call(*a, **k):
+            if not self.enabled or self.depth:
+                return orig(*a, **k)
+            e0 = torch.cuda.Event(enable_timing=True)
+            e1 = torch.cuda.Event(enable_timing=True)
+            e0.record()  # torch's current stream == the stream _native launches on
+            self.depth += 1
+            try:
+                r = orig(*a, **k)
+            finally:
+                self.depth -= 1
+            e1.record()
+            self.events.append((e0, e1))
+            return r
+        return call
 
     def mean_ms(self):
         if not self.events:
@@ -169,7 +178,7 @@ def main():
     chunks = [(lo, min(lo + phys, B)) for lo in range(0, B, phys)]
 
     k7 = KernelTimer(_native, "clip_reduce_noise" if world == 1 else "clip_reduce")
-    k1 = KernelTimer(_native, "linear_grad_sample")
+    k1 = KernelTimer(_native, "linear_grad_sample", "linear_grad_sample_group")
 
     graphed = None
     if not args.eager and len(chunks) == 1:
@@ -285,12 +294,19 @@ def pmc_traffic(config, B, n_chunks):
 def hot_path(native, gsm, opt, wl, chunks, steps):
     """Time K1..K7 alone on resident (A, G) pairs captured from one real step of the first chunk."""
     captured = []
-    orig = {n: getattr(native, n) for n in ("linear_grad_sample", "embedding_grad_sample", "layernorm_grad_sample")}
+    orig = {n: getattr(native, n) for n in ("linear_grad_sample", "linear_grad_sample_group", "embedding_grad_sample",
+                                            "layernorm_grad_sample")}
+    depth = [0]
 
     def cap(name):
         def f(*a, **k):
-            captured.append((name, a, k))
-            return orig[name](*a, **k)
+            if depth[0] == 0:  # the single-layer K1 call may forward to the grouped one: record the outermost only
+                captured.append((name, a, k))
+            depth[0] += 1
+            try:
+                return orig[name](*a, **k)
+            finally:
+                depth[0] -= 1
         return f
 
     for n in orig:
