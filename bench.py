@@ -42,6 +42,8 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--eager", action="store_true", help="launch every kernel from Python instead of replaying a hipGraph")
     ap.add_argument("--cpu-sample", type=int, default=None)
+    ap.add_argument("--no-gemm-tuning", action="store_true",
+                    help="leave the model's library GEMMs on hipBLASLt's default heuristics (no TunableOp)")
     ap.add_argument("--hooked-gru", action="store_true",
                     help="keep the reference's T-step GRU loop + per-call hooks instead of the fused K8 recurrence")
     return ap.parse_args()
@@ -148,6 +150,13 @@ def main():
     from dp_timeautodiff_amd.grad_sample import GradSampleModule
     from dp_timeautodiff_amd.optimizer import DistributedDPOptimizer, DPOptimizer
     _native.load()
+    tuned = False
+    if not args.no_gemm_tuning and args.config != "cfg5":
+        # hipBLASLt/rocBLAS solution per GEMM shape, chosen during the warm-up steps (seconds for cfg1-3; cfg5's
+        # 2048-wide GEMMs over 524k rows take ~6 ms per candidate run, i.e. minutes to tune, and are already at the
+        # library's peak: left on the default heuristics)
+        from dp_timeautodiff_amd import gemm_tuning
+        tuned = gemm_tuning.enable()
 
     wl = workloads.build(args.config, dev, batch=args.batch, seed_offset=rank * 1000,
                          fuse_recurrence=not args.hooked_gru)
@@ -261,6 +270,7 @@ def main():
                    "params": wl.n_params, "parallelism": f"dp{world}",
                    "step": "zero_grad+forward(K8)+backward(K8; per-sample grads K1/K3/K4)+DPOptimizer.step(K6,K7)+Adam(K9)",
                    "gru": "hooked T-step loop" if args.hooked_gru else "fused K8 recurrence",
+                   "library_gemms": "TunableOp (tuned in warm-up)" if tuned else "default heuristics",
                    "launch": ("hipGraph replay of the captured step" + (" (local part; all-reduce+noise+Adam eager)"
                               if world > 1 else "")) if graphed is not None else "eager"},
         "roofline": roof, "roofline_k1": k1_roof, "hot_path": hot, "final_loss": final_loss,

@@ -46,6 +46,7 @@ def main(argv=None):
     ap.add_argument("--load_path")
     ap.add_argument("--seed", type=int, default=None, help="fixes weights, DP noise and Poisson sampling")
     ap.add_argument("--no_graph", action="store_true")
+    ap.add_argument("--tune_gemms", action="store_true", help="let TunableOp pick the library GEMM per shape (warm-up)")
     args = ap.parse_args(argv)
     if not torch.cuda.is_available():
         sys.exit("dp_job.py needs a HIP device: the DP-SGD path has no CPU fallback")
@@ -70,7 +71,7 @@ def main(argv=None):
         emb_dim=args.emb_dim, time_dim=args.time_dim, lat_dim=args.lat_dim, device=dev, epsilon=args.epsilon,
         delta=args.delta, max_grad_norm=args.max_grad_norm, save_path=args.save_path, load_path=args.load_path,
         max_physical_batch_size=args.max_physical_batch_size, accountant=args.accountant,
-        use_graph=not args.no_graph, noise_seed=args.seed, sampler_seed=args.seed)
+        use_graph=not args.no_graph, tune_gemms=args.tune_gemms, noise_seed=args.seed, sampler_seed=args.seed)
     print(json.dumps({"epsilon_spent": out[-1], "target_epsilon": args.epsilon, "seconds": round(time.time() - t0, 2),
                       "samples": int(data.shape[0]), "epochs": args.n_epochs}))
 

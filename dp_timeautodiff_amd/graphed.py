@@ -17,6 +17,7 @@ from typing import Callable, Optional
 
 import torch
 
+from . import gemm_tuning
 from .grad_sample import GradSampleModule
 from .optimizer import DistributedDPOptimizer, DPOptimizer
 
@@ -90,6 +91,7 @@ class GraphedDPStep:
                 self._eager_step()
         torch.cuda.current_stream().wait_stream(side)
         torch.cuda.synchronize()
+        gemm_tuning.freeze()  # the warm-up steps have tuned every GEMM shape of the step; no timing runs under capture
         capacity = self.module.arena.capacity
         hook, opt.step_hook = opt.step_hook, None  # host-side accounting happens per replay, not at capture
         self.graph = torch.cuda.CUDAGraph()

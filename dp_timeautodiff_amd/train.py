@@ -35,8 +35,13 @@ def train_dp_autoencoder(processed_data: torch.Tensor, *, n_bins: int, n_cats: i
                          device, epsilon: float, delta: float = 1e-5, max_grad_norm: float = 1.0,
                          save_path: Optional[str] = None, load_path: Optional[str] = None, lambd: float = 0.7,
                          max_physical_batch_size: int = 128, accountant: str = "prv", use_graph: bool = True,
-                         noise_seed: Optional[int] = None, sampler_seed: Optional[int] = None, log=print):
+                         tune_gemms: bool = False, noise_seed: Optional[int] = None, sampler_seed: Optional[int] = None, log=print):
     device = torch.device(device)
+    if tune_gemms and device.type == "cuda":
+        # per-shape hipBLASLt/rocBLAS solution for the model's own GEMMs (+3 % at cfg2); the choice is timing-based, so
+        # two runs may round differently: leave it off where bit-identical resumption matters
+        from . import gemm_tuning
+        gemm_tuning.enable()
     N, seq_len, input_size = processed_data.shape
     ae = models.DeapStackDP(channels, batch_size, seq_len, n_bins, n_cats, n_nums, list(cards), input_size, hidden_size,
                             num_layers, emb_dim, time_dim, lat_dim).to(device)
