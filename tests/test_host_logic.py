@@ -120,3 +120,11 @@ def test_oracle_poisson_select_is_a_bernoulli_draw_per_sample():
     c = O.poisson_select(16, 0.5, seed=1, offset=0)
     assert np.array_equal(b, c[c >= 8] - 8)
     assert len(O.poisson_select(64, 0.0, 1, 0)) == 0 and len(O.poisson_select(64, 1.0, 1, 0)) == 64
+
+
+def test_gemm_tuning_is_a_no_op_without_a_gpu():
+    import torch
+    from dp_timeautodiff_amd import gemm_tuning
+    if not torch.cuda.is_available():
+        assert gemm_tuning.enable() is False
+    gemm_tuning.freeze()  # never raises, tuned or not
