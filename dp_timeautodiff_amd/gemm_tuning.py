@@ -34,5 +34,5 @@ def freeze() -> None:
     """Stop tuning new shapes (already chosen solutions stay in use).  Called before hipGraph capture: a tuning run
     launches and times kernels on its own, which a capturing stream does not allow."""
     tun = getattr(torch.cuda, "tunable", None)
-    if tun is not None and tun.is_enabled():
+    if tun is not None and torch.cuda.is_available() and tun.is_enabled():
         tun.tuning_enable(False)
