@@ -222,8 +222,7 @@ class DevicePoissonLoader:
             capacity = int(exp + 8.0 * (exp * (1.0 - self.sample_rate)) ** 0.5 + 8)
         self.capacity = max(1, min(int(capacity), self.num_samples))
         import os
-        self.seed = int.from_bytes(os.urandom(8), "little") if seed is None else int(seed)
-        self.seed = (self.seed + 0x9E3779B97F4A7C15 * rank) & (2**64 - 1)  # a distinct stream per rank
+        self.seed = int.from_bytes(os.urandom(8), "little") if seed is None else int(seed)  # the job's seed
         self.device = device
         self._blocks_per_draw = (self.num_samples + 3) // 4
         self._offset_dev = torch.zeros(1, dtype=torch.int64, device=device)  # advanced on device: graph-replayable
@@ -249,9 +248,16 @@ class DevicePoissonLoader:
     def __len__(self):
         return self.steps
 
+    @property
+    def key(self) -> int:
+        """Philox key of this rank's sampler stream: its own purpose tag (independent of the DP-noise stream under
+        the same seed, rng.py) and a distinct stream per rank."""
+        from .rng import RANK_STRIDE, stream_key
+        return stream_key((self.seed + RANK_STRIDE * self.rank) & (2**64 - 1), "sampler")
+
     def sample_static(self):
         """One Poisson draw into the static batch tensors (all device-side; capturable into a hipGraph)."""
-        self._native.poisson_sample(self.seed, 0, self.sample_rate, self.num_samples, self.idx, self.counts,
+        self._native.poisson_sample(self.key, 0, self.sample_rate, self.num_samples, self.idx, self.counts,
                                     offset_dev=self._offset_dev)
         self._offset_dev.add_(self._blocks_per_draw)
         self._overflow.add_((self.counts[1] > self.capacity).to(torch.int64))

@@ -48,9 +48,12 @@ class GraphedDPStep:
         self.warmup = warmup
         self.loader = loader
         self.replays = 0
-        # data-parallel: only the communication-free part is captured; the flat all-reduce, the shared-noise
-        # kernel and the wrapped optimizer run eagerly after each replay (4-15 launches)
+        # data-parallel: with an RCCL ("nccl") process group the flat all-reduce, the shared-noise kernel and the wrapped
+        # optimizer are nodes of the same graph (RCCL collectives are stream-ordered kernels: capturable).  Any other
+        # backend (gloo in CPU tests / one-GPU rehearsals) runs on the host: then only the communication-free part
+        # is captured and the exchange + noise + optimizer run eagerly after each replay (4-15 launches).
         self.distributed = isinstance(optimizer, DistributedDPOptimizer)
+        self.exchange_captured = False
 
     def _loss(self):
         if self.loader is None:
@@ -81,7 +84,8 @@ class GraphedDPStep:
             raise RuntimeError("capture a step outside BatchMemoryManager (pending skip-step signals)")
         if opt.generator is not None:
             raise RuntimeError("a torch noise generator cannot be captured; use the Philox stream (default)")
-        if not self.distributed:
+        full = not self.distributed or self._collective_capturable()
+        if full:
             _make_capturable(opt.original_optimizer)
             opt.enable_device_noise_offset()
         side = torch.cuda.Stream()
@@ -99,19 +103,30 @@ class GraphedDPStep:
             # thread_local: a collective library's watchdog thread (RCCL) may query events while this thread captures;
             # in the default "global" mode that would invalidate the capture
             with torch.cuda.graph(self.graph, capture_error_mode="thread_local"):
-                self.static_loss = self._local_part() if self.distributed else self._eager_step()
+                self.static_loss = self._eager_step() if full else self._local_part()
         finally:
             opt.step_hook = hook
+        self.exchange_captured = self.distributed and full
         if self.module.arena.capacity != capacity:
             raise RuntimeError("the per-sample-gradient arena grew during capture; warm up with the capture batch size")
         return self
 
+    def _collective_capturable(self) -> bool:
+        import torch.distributed as dist
+        try:
+            return dist.get_backend(self.optimizer.process_group) == "nccl"
+        except Exception:
+            return False
+
     def __call__(self) -> torch.Tensor:
         if self.graph is None:
             self.capture()
+        fa = self.optimizer._fused_adam
+        if fa is not None and (not self.distributed or self.exchange_captured):
+            fa._refresh_tables()  # lr / betas / weight_decay changed since capture (schedulers): the graph reads this table
         self.graph.replay()
         self.replays += 1
-        if self.distributed:
+        if self.distributed and not self.exchange_captured:
             self.optimizer.finish_step()  # calls the accountant hook itself
         elif self.optimizer.step_hook:
             self.optimizer.step_hook(self.optimizer)

@@ -29,6 +29,7 @@ import torch
 from torch.optim import Optimizer
 
 from . import _native, fused_adam
+from .rng import stream_key
 
 
 def _generate_seed() -> int:
@@ -131,6 +132,28 @@ class DPOptimizer(Optimizer):
             self._noise_offset_dev = torch.tensor([self._noise_offset], dtype=torch.int64, device=self.arena.device)
             self._noise_offset = 0
 
+    @property
+    def noise_key(self) -> int:
+        """Philox key of the DP-noise stream: derived from `noise_seed`, never the seed itself (rng.py), so a sampler
+        seeded with the same number draws an independent stream."""
+        return stream_key(self.noise_seed, "noise")
+
+    def set_noise_state(self, seed: int, offset: int):
+        """Restore the Philox stream position (checkpoints).  After enable_device_noise_offset() the live offset is
+        the device word; the host-side offset stays 0 then."""
+        self.noise_seed = int(seed)
+        if self._noise_offset_dev is not None:
+            self._noise_offset_dev.fill_(int(offset))
+            self._noise_offset = 0
+        else:
+            self._noise_offset = int(offset)
+
+    def noise_state(self):
+        off = int(self._noise_offset)
+        if self._noise_offset_dev is not None:
+            off += int(self._noise_offset_dev.item())
+        return {"seed": self.noise_seed, "offset": off}
+
     def inject_noise(self, flat_noise: torch.Tensor):
         """Parity/testing: use this [P_arena] tensor (already scaled by sigma*C) for the next real step."""
         self._injected_noise = flat_noise
@@ -194,7 +217,7 @@ class DPOptimizer(Optimizer):
         off = self._noise_offset
         if self._noise_offset_dev is None:
             self._noise_offset += arena.P // 4
-        return None, self.noise_seed, off, std
+        return None, self.noise_key, off, std
 
     def _advance_device_offset(self, arena, used_philox: bool):
         if used_philox and self._noise_offset_dev is not None:

@@ -209,10 +209,7 @@ class PrivacyEngine:
         checkpoint_dict["privacy_accountant_state_dict"] = self.accountant.state_dict()
         if optimizer is not None:
             checkpoint_dict["optimizer_state_dict"] = optimizer.state_dict()
-            dev_off = optimizer._noise_offset_dev  # graph-captured steps keep the Philox offset in a device word
-            checkpoint_dict["dp_noise_state"] = {
-                "seed": optimizer.noise_seed,
-                "offset": int(optimizer._noise_offset) + (int(dev_off.item()) if dev_off is not None else 0)}
+            checkpoint_dict["dp_noise_state"] = optimizer.noise_state()  # host offset + the graph's device word
         torch.save(checkpoint_dict, path, **(torch_save_kwargs or {}))
 
     def load_checkpoint(self, *, path: Union[str, os.PathLike, BinaryIO, IO[bytes]],
@@ -231,5 +228,5 @@ class PrivacyEngine:
                           f" but optimizer is {'' if optimizer else 'not'} provided.")
         ns = checkpoint.get("dp_noise_state")
         if optimizer is not None and ns:
-            optimizer.noise_seed, optimizer._noise_offset = ns["seed"], ns["offset"]
+            optimizer.set_noise_state(ns["seed"], ns["offset"])  # lands in the device word once a graph owns the offset
         return checkpoint

@@ -68,7 +68,7 @@ def train_dp_autoencoder(processed_data: torch.Tensor, *, n_bins: int, n_cats: i
         privacy_engine.accountant.load_state_dict(ckpt["privacy_accountant_state_dict"])
         optimizer_ae.load_state_dict(ckpt["optimizer_state_dict"])
         ns, ts = ckpt["dp_noise_state"], ckpt["train_state"]
-        optimizer_ae.noise_seed, optimizer_ae._noise_offset = int(ns["seed"]), int(ns["offset"])
+        optimizer_ae.set_noise_state(int(ns["seed"]), int(ns["offset"]))
         train_loader.seed = int(ts["sampler_seed"])
         train_loader._offset_dev.fill_(int(ts["sampler_offset"]))
         beta_t.fill_(float(ts["beta"]))

@@ -17,9 +17,17 @@ CONFIGS: Dict[str, dict] = {
     # name: kind, per-GPU batch, dims
     "cfg1": dict(kind="vae", B=64, T=24, K=13, H=200, desc="VAE dp_job.sh shape (AirQuality-like), B=64 T=24 K=13 H=200"),
     "cfg1_b50": dict(kind="vae", B=50, T=24, K=13, H=200, desc="VAE dp_job.sh literal batch 50"),
-    "cfg2": dict(kind="vae", B=1024, T=24, K=32, H=128, desc="VAE encoder/decoder DP-SGD, B=1024 T=24 K=32 H=128"),
+    "cfg2": dict(kind="vae", B=1024, T=24, K=32, H=128, cpu_sample=256,
+                 desc="VAE encoder/decoder DP-SGD, B=1024 T=24 K=32 H=128"),
     "cfg3": dict(kind="denoiser", B=4096, T=48, D=7, H=250, L=2, desc="latent diffusion denoiser DP-SGD, B=4096 T=48 H=250"),
-    "cfg5": dict(kind="vae", B=4096, T=256, K=128, H=512, desc="long-horizon VAE, T=256 K=128 H=512, 4096/GPU in physical chunks"),
+    # configs[3]: both models under DP-SGD, global batch 16384 over 8 GPUs = 2048 per GPU through the VAE and the denoiser
+    "cfg4": dict(kind="pair", parts=("cfg4_vae", "cfg4_den"), B=2048, cpu_sample=64,
+                 desc="full VAE + latent diffusion denoiser DP-SGD, 2048 samples per GPU through both models "
+                      "(global batch 16384 on 8 GPUs), one flat all-reduce of each model's clipped sum"),
+    "cfg4_vae": dict(kind="vae", B=2048, T=24, K=32, H=128, desc="cfg4's VAE (cfg2 model), 2048 per GPU"),
+    "cfg4_den": dict(kind="denoiser", B=2048, T=48, D=7, H=250, L=2, desc="cfg4's denoiser (cfg3 model), 2048 per GPU"),
+    "cfg5": dict(kind="vae", B=4096, T=256, K=128, H=512, phys=2048, cpu_sample=8, no_gemm_tuning=True,
+                 desc="long-horizon VAE, T=256 K=128 H=512, 4096/GPU in physical chunks"),
 }
 
 
@@ -45,6 +53,8 @@ def _linear_dims(model):
 
 def build(name: str, device, batch: int = None, seed_offset: int = 0, fuse_recurrence: bool = True) -> Workload:
     c = dict(CONFIGS[name])
+    if c["kind"] == "pair":
+        raise ValueError(f"{name} is a pair of models: build its parts {c['parts']} one by one")
     B = batch or c["B"]
     torch.manual_seed(0)
     gd = torch.Generator().manual_seed(1 + seed_offset)

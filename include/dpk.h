@@ -144,6 +144,9 @@ int dpk_clip_reduce(const float* GS, int64_t gs_stride, const float* clip, const
  * already scaled by std — the parity path), else noise_std * Philox4x32-10 normal #j of the stream
  * (seed, offset): element j uses Philox block (offset + j/4), lane j%4 — every rank of a data-parallel
  * job draws the same z from the same (seed, offset).  noise_std == 0 and noise == NULL -> z = 0.
+ * `seed` is the Philox KEY as is.  dpk_poisson_sample runs the same generator from block 0 too: a caller that seeds both
+ * from one user seed must hand each its own key (the Python host derives key = splitmix64(seed ^ purpose tag),
+ * dp_timeautodiff_amd/rng.py), or sampling and noise would share their uniforms.
  * offset_dev (nullable) points at a DEVICE uint64 added to `offset` when the kernel runs: a step captured into
  * a hipGraph keeps drawing fresh noise on every replay (the host, or a node of the graph, advances the word).
  */

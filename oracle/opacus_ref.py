@@ -305,6 +305,19 @@ class OracleDPOptimizer:
         return True
 
 
+def stream_key(seed: int, purpose: str) -> int:
+    """Philox key of one purpose's stream under a user seed: splitmix64(seed ^ tag).  The engine never keys the noise
+    kernel and the Poisson sampler with the same word (independence of sampling and noise is an assumption of the
+    DP analysis); this restates dp_timeautodiff_amd/rng.py for the checkers."""
+    m = (1 << 64) - 1
+    tag = {"noise": int.from_bytes(b"noise_dp", "big"), "sampler": int.from_bytes(b"poisson_", "big")}[purpose]
+    x = ((int(seed) & m) ^ tag) & m
+    x = (x + 0x9E3779B97F4A7C15) & m
+    x = ((x ^ (x >> 30)) * 0xBF58476D1CE4E5B9) & m
+    x = ((x ^ (x >> 27)) * 0x94D049BB133111EB) & m
+    return x ^ (x >> 31)
+
+
 def poisson_select(N: int, sample_rate: float, seed: int, offset: int) -> np.ndarray:
     """Indices a Poisson draw selects: j is in iff u_j < sample_rate (float32 compare), u_j = word (j & 3) of Philox
     block (offset + j // 4) mapped to (0,1) as in philox_normal.  Restates Opacus' UniformWithReplacementSampler

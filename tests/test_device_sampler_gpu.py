@@ -42,7 +42,7 @@ def test_loader_iterates_like_a_poisson_dataloader():
     blocks = (2000 + 3) // 4
     seen = []
     for k, (xb, yb) in enumerate(dl):
-        want = O.poisson_select(2000, 0.02, 21, k * blocks)
+        want = O.poisson_select(2000, 0.02, O.stream_key(21, "sampler"), k * blocks)
         assert np.array_equal(yb.cpu().numpy(), want)
         assert torch.equal(xb.cpu(), data[want])
         seen.append(len(want))
@@ -118,7 +118,7 @@ def test_graph_replay_draws_a_fresh_poisson_batch_every_step():
     for k in range(4):
         loss = g()
         draw = 2 + 1 + k  # 2 warm-up draws, 1 draw recorded at capture time (not executed), then the replays
-        want = O.poisson_select(N, q, 33, (2 + k) * blocks)
+        want = O.poisson_select(N, q, O.stream_key(33, "sampler"), (2 + k) * blocks)
         n_kept = int(dl.counts[0].item())
         assert n_kept == len(want), (k, draw)
         assert np.array_equal(dl.idx[:n_kept].cpu().numpy(), want)
@@ -168,7 +168,7 @@ def test_rank_shards_partition_the_dataset_and_draw_independent_streams():
     draws = [next(iter(dl))[0].cpu() for dl in loaders]
     for r, d in enumerate(draws):
         assert set(d.tolist()) <= set(owned[r].tolist())
-    assert len({dl.seed for dl in loaders}) == 3
+    assert len({dl.key for dl in loaders}) == 3
     # pooled over ranks the draw is a Poisson sample of the whole dataset at the same rate
     n = sum(len(d) for d in draws)
     assert abs(n - 1001 * 0.05) < 6 * (1001 * 0.05 * 0.95) ** 0.5

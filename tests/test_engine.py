@@ -273,9 +273,33 @@ def test_empty_poisson_batch_gives_pure_noise(dev):
     gsm(torch.zeros(0, 4, device=dev)).sum().backward()
     opt.step()
     from oracle import opacus_ref as O
-    z = O.philox_normal(opt.arena.P, 11, 0, 2.0) / 4.0
+    z = O.philox_normal(opt.arena.P, O.stream_key(11, "noise"), 0, 2.0) / 4.0
     w = opt.arena.window(net[0].weight)
     assert np.abs(net[0].weight.grad.cpu().reshape(-1).numpy() - z[w.offset:w.offset + 12]).max() < 1e-5
+
+
+def test_optimizer_keys_its_kernel_with_the_derived_noise_key(dev):
+    from dp_timeautodiff_amd import rng
+    from dp_timeautodiff_amd.grad_sample import GradSampleModule
+    from dp_timeautodiff_amd.optimizer import DPOptimizer
+    net = torch.nn.Linear(3, 2).to(dev)
+    gsm = GradSampleModule(net)
+    opt = DPOptimizer(torch.optim.SGD(net.parameters(), lr=0.1), noise_multiplier=1.0, max_grad_norm=1.0,
+                      expected_batch_size=2, noise_seed=5)
+    opt.attach_grad_sample_module(gsm)
+    assert opt.noise_key == rng.stream_key(5, "noise") != 5
+    _, key, off, std = opt._noise_args(opt.arena)
+    assert key == opt.noise_key and off == 0 and std == 1.0
+    # checkpoint round trip of the stream position, before and after a graph owns the offset
+    st = opt.noise_state()
+    assert st == {"seed": 5, "offset": opt.arena.P // 4}
+    opt.set_noise_state(5, 1000)
+    assert opt.noise_state()["offset"] == 1000
+    if dev.type == "cuda":
+        opt.enable_device_noise_offset()
+        assert opt.noise_state()["offset"] == 1000
+        opt.set_noise_state(5, 64)  # must land in the device word, not be added to it
+        assert opt.noise_state()["offset"] == 64 and opt._noise_offset == 0
 
 
 @pytest.mark.gpu

@@ -128,3 +128,22 @@ def test_gemm_tuning_is_a_no_op_without_a_gpu():
     if not torch.cuda.is_available():
         assert gemm_tuning.enable() is False
     gemm_tuning.freeze()  # never raises, tuned or not
+
+
+def test_noise_and_sampler_streams_are_domain_separated():
+    """one --seed used to key both the Poisson sampler and the DP noise with the same Philox word,
+    so the published noise was a function of the inclusion uniforms.  Equal user seeds must give unrelated streams."""
+    from dp_timeautodiff_amd import rng
+    from oracle import opacus_ref as O
+    for seed in (0, 1, 5, 2**63 + 5):
+        kn, ks = rng.stream_key(seed, "noise"), rng.stream_key(seed, "sampler")
+        assert kn != ks and kn != seed and ks != seed
+        assert kn == O.stream_key(seed, "noise") and ks == O.stream_key(seed, "sampler")  # checker restates it
+        ctr = np.zeros((4, 4), np.uint32)
+        ctr[:, 0] = np.arange(4)
+        key = lambda k: np.array([k & 0xFFFFFFFF, k >> 32], np.uint32)
+        bn, bs = O.philox4x32_10(ctr, key(kn)), O.philox4x32_10(ctr, key(ks))
+        assert not (bn == bs).any()  # block 0..3: not one 32-bit word in common
+    # per-rank sampler keys differ, and none of them is the noise key
+    ks = {rng.stream_key((9 + rng.RANK_STRIDE * r) & (2**64 - 1), "sampler") for r in range(8)}
+    assert len(ks) == 8 and rng.stream_key(9, "noise") not in ks

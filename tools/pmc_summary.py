@@ -19,7 +19,15 @@ write, _ = load(sys.argv[2])
 out = {"note": "per-launch means; FETCH_SIZE KB x 2 (gfx950 wide-read correction) x 1024; WRITE_SIZE KB x 1024",
        "kernels": {k: {"launches": n[k], "fetch_bytes": fetch[k] * 2 * 1024, "write_bytes": write.get(k, 0.0) * 1024}
                    for k in fetch}}
+# tools/hotpath_replay.py runs K1 once more than K7 (the capturing backward pass has no optimizer tail):
+passes_k7 = max((n[k] for k in n if k.startswith("clip_factor_kernel")), default=0)
+if passes_k7:
+    tot = lambda pred, passes: sum((out["kernels"][k]["fetch_bytes"] + out["kernels"][k]["write_bytes"]) * n[k]
+                                   for k in out["kernels"] if pred(k)) / passes
+    out["k1_bytes_per_step"] = tot(lambda k: k.startswith("linear_gs"), passes_k7 + 1)
+    out["k7_bytes_per_step"] = tot(lambda k: k.startswith("clip_reduce_kernel") or k.startswith("finalize_kernel"), passes_k7)
 root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 json.dump(out, open(os.path.join(root, "profiles", f"{sys.argv[3]}_pmc_traffic.json"), "w"), indent=1)
+print({k: v for k, v in out.items() if k.endswith("per_step")})
 for k, v in out["kernels"].items():
     print(f"{k:36s} n={v['launches']:4d} fetch {v['fetch_bytes']/1e6:10.2f} MB  write {v['write_bytes']/1e6:10.2f} MB")
