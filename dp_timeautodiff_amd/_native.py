@@ -45,6 +45,8 @@ EXPORTS = {
     "dpk_clip_reduce_noise": (c_int, [c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_uint64, c_uint64,
                                       c_void_p, c_float, c_float, c_void_p, c_void_p, c_int, c_int64, c_void_p, c_int64,
                                       c_void_p]),
+    "dpk_clip_reduce_noise_static": (c_int, [c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_uint64, c_uint64,
+                                             c_void_p, c_float, c_float, c_void_p, c_void_p, c_int, c_int64, c_void_p]),
     "dpk_philox_normal": (c_int, [c_void_p, c_int64, c_uint64, c_uint64, c_float, c_void_p]),
     "dpk_adam_step": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_int64, c_void_p]),
     "dpk_lstm_pack_forward": (c_int, [c_void_p, c_void_p, c_int, c_int, c_void_p]),
@@ -308,6 +310,27 @@ def clip_reduce_noise(gs: FlatView, clip, summed_in, noise, seed: int, offset: i
                                       seed & (2**64 - 1), offset & (2**64 - 1), _ptr(offset_dev), float(noise_std),
                                       float(inv_scale), _ptr(summed_out), _ptr(grad), B, P, wp, wb, _stream())
     _check(rc, "dpk_clip_reduce_noise")
+
+
+STATIC_SCRATCH_BYTES = 16 * 1024 * 1024
+
+
+def clip_reduce_noise_static(gs: FlatView, clip, summed_in, noise, seed: int, offset: int, noise_std: float,
+                             inv_scale: float, summed_out, grad, B: int, offset_dev=None):
+    """dpk_clip_reduce_noise without a workspace argument: the split-B partials live in the library's own static
+    device array (no allocation on the call path).  Calls on one GPU must not overlap."""
+    _req(gs.base, "GS"); _req(clip, "clip"); _req(grad, "grad")
+    P = gs.numel
+    for t, n in ((summed_in, "summed_in"), (noise, "noise"), (summed_out, "summed_out"), (grad, "grad")):
+        if t is not None and t.numel() < P:
+            raise DpkError(f"clip_reduce_noise_static: {n} shorter than P")
+    if clip.numel() < B or gs.base.shape[0] < B:
+        raise DpkError("clip_reduce_noise_static: buffers shorter than the batch")
+    rc = load().dpk_clip_reduce_noise_static(gs.ptr, gs.stride, _ptr(clip), _ptr(summed_in), _ptr(noise),
+                                             seed & (2**64 - 1), offset & (2**64 - 1), _ptr(offset_dev),
+                                             float(noise_std), float(inv_scale), _ptr(summed_out), _ptr(grad), B, P,
+                                             _stream())
+    _check(rc, "dpk_clip_reduce_noise_static")
 
 
 def philox_normal(out: torch.Tensor, seed: int, offset: int, std: float):

@@ -9,6 +9,8 @@
 // result is reproducible (no float atomics).
 #include <stdlib.h>
 
+#include <mutex>
+
 #include "dpk_common.h"
 #include "philox.h"
 
@@ -242,6 +244,56 @@ int clip_reduce_impl(const float* GS, int64_t gs_stride, const float* clip, cons
 
 }  // namespace
 
+// ---- scratch of dpk_clip_reduce_noise_static ------------------------------------------------------------------
+// K7's split-B partial sums [nsplit, P] for callers that may not allocate.  pick_nsplit() never asks for more than
+// (2400 + blocks_x / 2) * 1024 floats with blocks_x <= 1600, i.e. 13.1 MB, so 16 MiB covers every (B, P); the size
+// check in the entry point guards that bound.  One copy per GPU the library runs on, held until the process ends.
+// In host code the array's NAME is only a handle: the device address comes from hipGetSymbolAddress, per device.
+static __device__ __align__(256) float scratch[DPK_STATIC_SCRATCH_BYTES / sizeof(float)];
+
+namespace {
+
+constexpr int MAX_DEVICES = 64;
+std::mutex scratch_mu;
+float* scratch_ptr[MAX_DEVICES] = {nullptr};
+
+// Device address of `scratch` on the CURRENT device (looked up once per device, with that device current).
+int scratch_for_current_device(float** out) {
+    int dev = -1;
+    hipError_t e = hipGetDevice(&dev);
+    if (e != hipSuccess) return (int)e;
+    if (dev < 0 || dev >= MAX_DEVICES) return DPK_ERANGE;
+    std::lock_guard<std::mutex> lock(scratch_mu);
+    if (scratch_ptr[dev] == nullptr) {
+        void* p = nullptr;
+        e = hipGetSymbolAddress(&p, HIP_SYMBOL(scratch));
+        if (e != hipSuccess) return (int)e;
+        if (p == nullptr || !dpk_aligned16(p)) return DPK_EALIGN;
+        scratch_ptr[dev] = (float*)p;
+    }
+    *out = scratch_ptr[dev];
+    return DPK_OK;
+}
+
+}  // namespace
+
+extern "C" int dpk_clip_reduce_noise_static(const float* GS, int64_t gs_stride, const float* clip,
+                                            const float* summed_in, const float* noise, uint64_t seed,
+                                            uint64_t offset, const uint64_t* offset_dev, float noise_std,
+                                            float inv_scale, float* summed_out, float* grad, int B, int64_t P,
+                                            void* stream) {
+    if (B < 0 || P <= 0) return DPK_EINVAL;
+    const int64_t need = dpk_clip_reduce_workspace(B, P);
+    if (need > (int64_t)DPK_STATIC_SCRATCH_BYTES) return DPK_ESCRATCH;
+    float* ws = nullptr;
+    if (need > 0) {  // the partials are fully overwritten before they are read: nothing to clear between calls
+        const int rc = scratch_for_current_device(&ws);
+        if (rc != DPK_OK) return rc;
+    }
+    return clip_reduce_impl(GS, gs_stride, clip, summed_in, noise, seed, offset, offset_dev, noise_std, inv_scale,
+                            summed_out, grad, true, B, P, ws, need, stream);
+}
+
 extern "C" int dpk_normsq_slots(int64_t P) {
     if (P <= 0) return DPK_EINVAL;
     const int64_t n = (P + K5_CHUNK - 1) / K5_CHUNK;
@@ -316,6 +368,7 @@ extern "C" const char* dpk_error_string(int code) {
         case DPK_ERANGE: return "dimension outside the supported range";
         case DPK_EALIGN: return "pointer or stride not aligned as required (16 bytes / multiple of 4 floats)";
         case DPK_ESLOTS: return "normsq partial row too short for this call's slots";
+        case DPK_ESCRATCH: return "input needs more split-B scratch than the library's static buffer holds (DPK_STATIC_SCRATCH_BYTES)";
         default: return code > 0 ? hipGetErrorString((hipError_t)code) : "unknown dpk error";
     }
 }

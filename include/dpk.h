@@ -13,7 +13,8 @@
  *   - plain C types only; pointers are DEVICE pointers (hipMalloc / torch.Tensor.data_ptr()),
  *     fp32 row-major, contiguous unless a stride argument says otherwise;
  *   - `stream` is a hipStream_t passed as void* (torch.cuda.current_stream().cuda_stream);
- *     every call is asynchronous and stream-ordered, allocates nothing, keeps no global state;
+ *     every call is asynchronous and stream-ordered and allocates nothing; the only process-wide state is two
+ *     per-device caches (CU count; device address of dpk_clip_reduce_noise_static's scratch array);
  *   - return 0 on success, a negative DPK_E* code on an argument error (nothing launched), or a
  *     positive hipError_t if the launch failed.  Nothing throws.
  *   - per-sample squared norms are produced as *partials*: every grad-sample kernel writes, for
@@ -37,6 +38,7 @@ extern "C" {
 #define DPK_ERANGE (-2)   /* dimension beyond what the kernel's grid or LDS plan supports */
 #define DPK_EALIGN (-3)   /* pointer or stride not aligned as documented */
 #define DPK_ESLOTS (-4)   /* normsq partial row too short for the slots this call writes */
+#define DPK_ESCRATCH (-5) /* dpk_clip_reduce_noise_static: input needs more scratch than DPK_STATIC_SCRATCH_BYTES */
 
 int dpk_version(void);
 const char* dpk_error_string(int code);
@@ -159,6 +161,23 @@ int dpk_clip_reduce_noise(const float* GS, int64_t gs_stride, const float* clip,
                           const float* noise, uint64_t seed, uint64_t offset, const uint64_t* offset_dev,
                           float noise_std, float inv_scale, float* summed_out, float* grad, int B, int64_t P,
                           void* workspace, int64_t workspace_bytes, void* stream);
+
+/*
+ * K7 fused, for callers that cannot allocate.  No counterpart in the reference: it exists for hosts that may not call
+ * hipMalloc around the step — code under hipGraph capture, tight serving/training loops, harnesses that forbid it.
+ * Same arguments, kernels and results (bit for bit) as dpk_clip_reduce_noise, minus the workspace: the split-B
+ * partial sums live in a file-scope __device__ array of DPK_STATIC_SCRATCH_BYTES inside the library (one copy per
+ * GPU the library runs on, held until the process ends; its device address is looked up once per device on the
+ * first call there).  The call allocates and frees nothing.  Inputs whose split needs more than that return
+ * DPK_ESCRATCH and launch nothing (with today's split rule the need never exceeds 13.1 MB).  All calls on one GPU share
+ * that GPU's array: calls that overlap in time on one GPU (two streams, two threads) race — serialise them.  Nothing
+ * has to be cleared between calls: every partial a call reads it has written itself.
+ */
+#define DPK_STATIC_SCRATCH_BYTES (16 * 1024 * 1024)
+int dpk_clip_reduce_noise_static(const float* GS, int64_t gs_stride, const float* clip, const float* summed_in,
+                                 const float* noise, uint64_t seed, uint64_t offset, const uint64_t* offset_dev,
+                                 float noise_std, float inv_scale, float* summed_out, float* grad, int B, int64_t P,
+                                 void* stream);
 
 /* Philox normal stream on its own (tests; also lets host code pre-draw the shared noise). */
 int dpk_philox_normal(float* out, int64_t n, uint64_t seed, uint64_t offset, float std, void* stream);

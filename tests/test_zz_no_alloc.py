@@ -1,0 +1,87 @@
+"""dpk_clip_reduce_noise_static — K7 for callers that cannot allocate (include/dpk.h).
+
+Through the C-ABI, against the existing entry point dpk_clip_reduce_noise on the same inputs: same kernels, same split,
+so the bar is bit-exact.  Two calls in a row, the second with a smaller input (the library's static scratch keeps the
+first call's partial sums: nothing of them may leak into the second result), plus the float64 formula of Opacus'
+clip_and_accumulate / add_noise / scale_grad at 1e-5.
+"""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _case(B, P, seed):
+    g = torch.Generator().manual_seed(seed)
+    gs = torch.randn(B, P, generator=g).cuda()
+    clip = torch.rand(B, generator=g).cuda()
+    noise = torch.randn(P, generator=g).cuda()
+    prev = torch.randn(P, generator=g).cuda()
+    return gs, clip, noise, prev
+
+
+def _both(nat, gs, clip, noise, prev, B, P, philox):
+    full = nat.FlatView(gs, 0, P)
+    need = nat.clip_reduce_workspace(B, P)
+    assert need > 0, "the case must use split-B partials, or the scratch is not exercised"
+    assert need <= nat.STATIC_SCRATCH_BYTES
+    ws = torch.empty(need // 4, device="cuda")
+    out = {}
+    for name in ("ref", "static"):
+        summed = torch.full((P,), float("nan"), device="cuda")
+        grad = torch.full((P,), float("nan"), device="cuda")
+        args = (full, clip, prev, None if philox else noise, 77, 5, 1.5 if philox else 0.0, 1.0 / B, summed, grad, B)
+        if name == "ref":
+            nat.clip_reduce_noise(*args, ws)
+        else:
+            nat.clip_reduce_noise_static(*args)
+        torch.cuda.synchronize()
+        out[name] = (summed.cpu(), grad.cpu())
+    return out
+
+
+@pytest.mark.parametrize("philox", [False, True])
+def test_static_scratch_entry_point_matches_workspace_entry_point(philox):
+    from dp_timeautodiff_amd import _native as nat
+    nat.load()
+    # first call: 4 splits over 200k columns; second, smaller in both dimensions: 2 splits over 100k columns
+    for B, P, seed in ((512, 200_000, 1), (300, 100_000, 2)):
+        gs, clip, noise, prev = _case(B, P, seed)
+        out = _both(nat, gs, clip, noise, prev, B, P, philox)
+        assert torch.equal(out["static"][0], out["ref"][0]), (B, P)
+        assert torch.equal(out["static"][1], out["ref"][1]), (B, P)
+        assert torch.isfinite(out["static"][1]).all()
+        if not philox:  # injected noise: the float64 formula
+            want_s = (clip.double().cpu()[:, None] * gs.double().cpu()).sum(0) + prev.double().cpu()
+            want_g = (want_s + noise.double().cpu()) / B
+            err_s = float((out["static"][0].double() - want_s).abs().max() / want_s.abs().max())
+            err_g = float((out["static"][1].double() - want_g).abs().max() / want_g.abs().max())
+            assert err_s < 1e-5 and err_g < 1e-5, (err_s, err_g)
+
+
+def test_static_entry_point_makes_no_allocation_and_checks_its_arguments():
+    from dp_timeautodiff_amd import _native as nat
+    lib = nat.load()
+    B, P = 512, 200_000
+    gs, clip, noise, prev = _case(B, P, 3)
+    summed, grad = torch.empty(P, device="cuda"), torch.empty(P, device="cuda")
+    full = nat.FlatView(gs, 0, P)
+    nat.clip_reduce_noise_static(full, clip, None, noise, 0, 0, 0.0, 1.0, summed, grad, B)  # first use on this device
+    torch.cuda.synchronize()
+    free0, _ = torch.cuda.mem_get_info()
+    for _ in range(3):
+        nat.clip_reduce_noise_static(full, clip, None, noise, 0, 0, 0.0, 1.0, summed, grad, B)
+    torch.cuda.synchronize()
+    free1, _ = torch.cuda.mem_get_info()
+    assert free1 == free0  # device memory untouched by the calls
+    # argument errors come back as codes, nothing is launched
+    import ctypes
+    rc = lib.dpk_clip_reduce_noise_static(None, P, ctypes.c_void_p(clip.data_ptr()), None, None, 0, 0, None, 0.0, 1.0,
+                                          None, ctypes.c_void_p(grad.data_ptr()), B, P, None)
+    assert rc == -1
+    assert b"static buffer" in lib.dpk_error_string(-5)
+    # every input the split rule can produce fits the static scratch (the DPK_ESCRATCH guard is a bound, not a case)
+    worst = max(nat.clip_reduce_workspace(Bq, Pq) for Bq in (128, 256, 4096, 65536)
+                for Pq in (4096, 409_600, 1_638_400 - 1024, 1_638_400, 1_638_400 + 1024, 50_000_000))
+    assert 0 < worst <= nat.STATIC_SCRATCH_BYTES
