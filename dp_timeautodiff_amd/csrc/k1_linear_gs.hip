@@ -212,32 +212,14 @@ __global__ void __launch_bounds__(NW * 64) linear_gs_kernel(const float* __restr
 }
 
 
-// ---- persistent, prefetching variant (T <= 48; lab: tools/lab/k1_lab.hip variant Q) --------------------------
-// At the sizes of the real step (arena of several GB, operands beyond the Infinity Cache) the launch-per-tile
-// kernel above loses 15-20 %: a workgroup's operand loads are issued after the previous occupant's stores and
-// queue behind them in the CU's in-order vector-memory pipe, so staging and storing alternate instead of
-// overlapping.  Here a fixed grid (2 workgroups per CU) walks the (sample, tile) items of its XCD; the operands of
-// item i+1 are fetched into registers BEFORE item i's MFMAs and stores are issued (the loads sit ahead of the
-// stores in the pipe and land under the MFMAs), and the two barriers per item wait for LDS only, never for the
-// wave's own stores.  The whole [T x RS] / [T x CS] slices stay resident (T <= 48: 74 KB), every wave computes a
-// unit and streams it out at once, as in STREAM mode.
+// ---- persistent kernels (T <= 48) -------------------------------------------------------------------------------
+// At the sizes of the real step (arena of several GB, operands beyond the Infinity Cache) the launch-per-tile kernel
+// above loses 15-20 %: a workgroup's operand loads are issued after the previous occupant's stores and queue behind
+// them in the CU's in-order vector-memory pipe, so staging and storing alternate instead of overlapping.  A persistent
+// kernel runs a fixed grid over the (sample, tile) items of its XCD and fetches the operands of item i+1 into registers
+// BEFORE item i's MFMAs and stores are issued (the loads sit ahead of the stores in the pipe and land under the
+// MFMAs); its barriers wait for LDS only, never for the wave's own stores.
 __device__ __forceinline__ void lds_only_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
-
-__device__ __forceinline__ f32x4 fetch4(const float* __restrict__ g, int t, int T, int col, int dim, int ld) {
-    f32x4 v = {0.f, 0.f, 0.f, 0.f};
-    if (t < T) {
-        const float* src = g + (int64_t)t * ld + col;
-        const int left = dim - col;
-        if (left >= 4) {
-            v = *reinterpret_cast<const f32x4u*>(src);
-        } else if (left > 0) {
-            v[0] = src[0];
-            if (left > 1) v[1] = src[1];
-            if (left > 2) v[2] = src[2];
-        }
-    }
-    return v;
-}
 
 // Up to DPK_K1_MAX_JOBS same-shape layers (the six gate Linears of a GRU pair) share one launch: by-value table.
 struct K1Jobs {
@@ -249,147 +231,225 @@ struct K1Jobs {
     int n;
 };
 
-// NG / NA: float4 registers per thread that hold the next item's G / A slice (>= ceil(Tp*RS/4/NTHR), same for CS).
-template <int NW, int RS, int CS, int NT, int NG, int NA, bool NTS>
-__global__ void __launch_bounds__(NW * 64) linear_gs_persist_kernel(
+// ---- persistent, "wide unit" variant (round 2): the whole-line path of every large layer at T <= 48 -------------
+// Same shape as linear_gs_persist_kernel (a fixed grid walks the (sample, tile) items of its XCD; the operands of item
+// i+1 are fetched into registers before item i's MFMAs and stores are issued), with what cycle stamps on that kernel
+// (tools/lab/k1_stamps.py) showed to cost the most taken out:
+//   * a wave's unit is 32 rows x 128 columns with the columns PERMUTED over the lanes: lane c of a half-wave owns the
+//     four adjacent columns 4c..4c+3, one per MFMA of the k-step.  One ds_read_b32 (G) and one ds_read_b128 (A: the
+//     lane's four columns are contiguous in the [t][col] slice) feed FOUR v_mfma_f32_32x32x2_f32 (1.5 LDS instructions
+//     per MFMA before, 0.5 now), issued one k-step ahead of their use; the four accumulators hold four adjacent
+//     output elements per register index, so a row leaves as 16-byte non-temporal stores: 16 store instructions of
+//     1 KiB per unit instead of 64 of 256 B.  8 units per 128 x 256 tile = one per wave;
+//   * every global access is a BUFFER instruction whose guard is the hardware range check (out-of-tile lanes get an
+//     out-of-range offset): no branch around a memory instruction, so the wait before staging is a counted vmcnt(N)
+//     that leaves the wave's own stores in flight (it was vmcnt(0): every wave drained its stores once per item);
+//   * the item walk is a few scalar adds per item (it was 64-bit divisions: 3-6k of a 22.8k-cycle item);
+//   * the bias slice is the sum of the G values the wave feeds its MFMAs anyway (it was a serial T-step loop in two
+//     waves that the other six waited for at the barrier).
+// The k order of every output element is unchanged (t ascending): weights bit-identical to the narrow-unit kernel;
+// the bias sums even and odd time steps separately (two half-waves) before adding them.
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+#ifndef DPK_K1_STORE_AUX
+#define DPK_K1_STORE_AUX 2  // buffer-store cache policy of the per-sample gradients: nt (bit 1); sc1 = bit 4, sc0 = bit 0
+#endif
+constexpr unsigned OOB = 0x80000000u;  // beyond any descriptor's range: loads return 0, stores are dropped
+
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void* base, int64_t bytes) {
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, (int)bytes, 0x00020000);
+}
+
+
+
+// Elements at or beyond `left` (what is left of the row) of a 4-float group are not the tile's: zero them.  Applied
+// when the group is staged, not when it is fetched, so that nothing waits on a prefetch load early.
+__device__ __forceinline__ f32x4 mask4(f32x4 v, int left) {
+    v[1] = left > 1 ? v[1] : 0.f;
+    v[2] = left > 2 ? v[2] : 0.f;
+    v[3] = left > 3 ? v[3] : 0.f;
+    return v;
+}
+
+template <int NG, int NA>
+__global__ void __launch_bounds__(512) linear_gs_persist_wide_kernel(
     const K1Jobs jobs, float* __restrict__ normsq_part, int64_t part_stride, int B, int T, int in_f, int out_f,
     int64_t gs_stride, int ld_w, int ld_g, float g_scale, int tiles_m, int tiles_n) {
-    constexpr int NTHR = NW * 64;
-    constexpr int NCG = CS / (32 * NT);
-    constexpr int UNITS = (RS / 32) * NCG;
+    constexpr int NW = 8, RS = 128, CS = 256, NTHR = NW * 64;
     constexpr int R4 = RS / 4, C4 = CS / 4;
-    extern __shared__ __attribute__((aligned(16))) float smem[];  // [Tp][RS] G slice, [Tp][CS] A slice, red[2][NW]
-    const int Tp = (T + 1) & ~1;  // MFMA consumes k in pairs; the pad row is zero-filled
+    extern __shared__ __attribute__((aligned(16))) float smem[];  // [Tp][RS] G, [Tp][CS] A, 2 pad rows, red[2][NW]
+    const int Tp = (T + 1) & ~1;
     float* sG = smem;
     float* sA = smem + Tp * RS;
-    float* red = sA + Tp * CS;
+    float* red = sA + Tp * CS + 2 * CS;  // 2 rows of padding: the one-k-step-ahead operand reads stay inside LDS
     const int totG = Tp * R4, totA = Tp * C4;
+    const int ksteps = Tp >> 1;
 
-    // ---- XCD-aware item walk: this workgroup's XCD owns the samples b = xcd (mod 8) ----------------------
+    // ---- XCD-aware item walk in (job, sample slot, tile row, tile column) form -----------------------------------
     const int ntile = tiles_m * tiles_n;
     const int xcd = blockIdx.x & 7;
-    const int nbx = gridDim.x >> 3;          // workgroups per XCD (grid is a multiple of 8)
-    const int nsx = (B - xcd + 7) / 8;       // samples on this XCD
-    const int64_t per_job = (int64_t)nsx * ntile;
-    const int64_t nitems = per_job * jobs.n;  // job-major: (job, sample, tile)
-    int64_t item = blockIdx.x >> 3;
-    if (item >= nitems) return;              // uniform
+    const int nbx = gridDim.x >> 3;        // workgroups per XCD (grid is a multiple of 8)
+    const int nsx = (B - xcd + 7) / 8;     // samples on this XCD: b = 8 s + xcd
+    struct Item {
+        int job, s, tm, tn;
+    };
+    const int d_s = nbx / ntile, d_tm = (nbx % ntile) / tiles_n, d_tn = nbx % tiles_n;
+    auto advance = [&](Item x) {
+        x.tn += d_tn;
+        if (x.tn >= tiles_n) { x.tn -= tiles_n; ++x.tm; }
+        x.tm += d_tm;
+        if (x.tm >= tiles_m) { x.tm -= tiles_m; ++x.s; }
+        x.s += d_s;
+        while (x.s >= nsx && x.job < jobs.n) { x.s -= nsx; ++x.job; }  // job == jobs.n: past the last item
+        return x;
+    };
+    Item cur;
+    {
+        const int w = blockIdx.x >> 3;  // first item of this workgroup (job 0)
+        cur.job = 0;
+        cur.s = w / ntile;
+        cur.tm = (w % ntile) / tiles_n;
+        cur.tn = w % tiles_n;
+        while (cur.s >= nsx && cur.job < jobs.n) { cur.s -= nsx; ++cur.job; }
+    }
+    if (nsx <= 0 || cur.job >= jobs.n) return;  // uniform
 
-    const int lane = threadIdx.x & 63;
-    const int wave = threadIdx.x >> 6;
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // provably wave-uniform: scalar branches, SGPR math
     const int l31 = lane & 31;
     const int lh = lane >> 5;
+    const int mr = wave >> 1, cg = wave & 1;  // this wave's 32 x 128 unit inside the 128 x 256 tile
 
     f32x4 rg[NG], ra[NA];
-    auto prefetch = [&](int64_t it) {
-        const int job = (int)(it / per_job);
-        const int64_t rem = it - job * per_job;
-        const int b = (int)(rem / ntile) * 8 + xcd;
-        const int tile = (int)(rem % ntile);
-        const int tm = tile / tiles_n, tn = tile - tm * tiles_n;
-        const float* Gb = jobs.G[job] + (int64_t)b * T * ld_g;
-        const float* Ab = jobs.A[job] + (int64_t)b * T * in_f;
+    auto prefetch = [&](const Item& x) {
+        // the sample's slices: G rows have stride ld_g (out_f valid columns), A rows are dense
+        const int64_t b = x.s * 8 + xcd;
+        const auto rsG = make_rsrc(jobs.G[x.job] + b * T * ld_g, ((int64_t)(T - 1) * ld_g + out_f) * 4);
+        const auto rsA = make_rsrc(jobs.A[x.job] + b * T * in_f, (int64_t)T * in_f * 4);
 #pragma unroll
         for (int k = 0; k < NG; ++k) {
-            const int idx = threadIdx.x + k * NTHR;
-            const int t = idx / R4, c = (idx - t * R4) * 4;
-            rg[k] = fetch4(Gb, idx < totG ? t : T, T, tm * RS + c, out_f, ld_g);
+            const int idx = tid + k * NTHR;
+            const int t = idx / R4, col = x.tm * RS + (idx - t * R4) * 4;
+            const unsigned off = (t < T && col < out_f) ? (unsigned)(t * ld_g + col) * 4u : OOB;
+            rg[k] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsG, off, 0, 0));
         }
 #pragma unroll
         for (int k = 0; k < NA; ++k) {
-            const int idx = threadIdx.x + k * NTHR;
-            const int t = idx / C4, c = (idx - t * C4) * 4;
-            ra[k] = fetch4(Ab, idx < totA ? t : T, T, tn * CS + c, in_f, in_f);
+            const int idx = tid + k * NTHR;
+            const int t = idx / C4, col = x.tn * CS + (idx - t * C4) * 4;
+            const unsigned off = (t < T && col < in_f) ? (unsigned)(t * in_f + col) * 4u : OOB;
+            ra[k] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsA, off, 0, 0));
+        }
+    };
+    auto stage = [&](const Item& x) {  // prefetched registers (operands of item x) -> LDS
+#pragma unroll
+        for (int k = 0; k < NG; ++k) {
+            const int idx = tid + k * NTHR;
+            const int left = out_f - (x.tm * RS + (idx % R4) * 4);
+            if (idx < totG) *reinterpret_cast<f32x4*>(sG + idx * 4) = mask4(rg[k], left) * g_scale;
+        }
+#pragma unroll
+        for (int k = 0; k < NA; ++k) {
+            const int idx = tid + k * NTHR;
+            const int left = in_f - (x.tn * CS + (idx % C4) * 4);
+            if (idx < totA) *reinterpret_cast<f32x4*>(sA + idx * 4) = mask4(ra[k], left);
         }
     };
 
-    prefetch(item);
+    prefetch(cur);
     int parity = 0;
-    while (true) {
-#pragma unroll
-        for (int k = 0; k < NG; ++k) {
-            const int idx = threadIdx.x + k * NTHR;
-            if (idx < totG) *reinterpret_cast<f32x4*>(sG + idx * 4) = rg[k] * g_scale;
-        }
-#pragma unroll
-        for (int k = 0; k < NA; ++k) {
-            const int idx = threadIdx.x + k * NTHR;
-            if (idx < totA) *reinterpret_cast<f32x4*>(sA + idx * 4) = ra[k];
-        }
+    bool more = true;
+    // one item: stage its prefetched operands, prefetch the next item's, contract, store, publish the squared norm
+    auto do_item = [&]() {
+        stage(cur);
         lds_only_barrier();
-        const int job = (int)(item / per_job);
-        const int64_t rem = item - job * per_job;
-        const int b = (int)(rem / ntile) * 8 + xcd;
-        const int tile = (int)(rem % ntile);
-        const int tm = tile / tiles_n, tn = tile - tm * tiles_n;
-        const int m0 = tm * RS, n0 = tn * CS;
-        float* __restrict__ GSw = jobs.W[job];
-        float* __restrict__ GSb = jobs.Bi[job];
-        const int slot0 = jobs.slot0[job];
-        const int64_t nitem = item + nbx;
-        const bool has_next = nitem < nitems;
-        if (has_next) prefetch(nitem);  // ahead of this item's stores in the vector-memory pipe
+        const Item nxt = advance(cur);
+        const bool has_next = nxt.job < jobs.n;
+        if (has_next) prefetch(nxt);  // ahead of this item's stores in the vector-memory pipe
 
-        float sq = 0.f;
-        float* out = GSw + (int64_t)b * gs_stride;
-        for (int u = wave; u < UNITS; u += NW) {
-            const int mr = u / NCG, cg = u - mr * NCG;
-            const int wrow0 = m0 + mr * 32;
-            const int wcol0 = n0 + cg * (32 * NT);
-            if (wrow0 >= out_f || wcol0 >= in_f) continue;
-            f32x16 acc[NT];
+        const int m0 = cur.tm * RS, n0 = cur.tn * CS;
+        const int64_t b = cur.s * 8 + xcd;
+        const bool live = (m0 + mr * 32 < out_f) && (n0 + cg * 128 < in_f);
+        f32x16 acc[4];
 #pragma unroll
-            for (int j = 0; j < NT; ++j)
+        for (int j = 0; j < 4; ++j)
 #pragma unroll
-                for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
+            for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
+        float bsum = 0.f;
+        if (live) {
             const float* pg = sG + lh * RS + mr * 32 + l31;
-            const float* pa = sA + lh * CS + cg * (32 * NT) + l31;
-            for (int kk = 0; kk < Tp; kk += 2) {
-                const float a = pg[kk * RS];
-#pragma unroll
-                for (int j = 0; j < NT; ++j)
-                    acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, pa[kk * CS + j * 32], acc[j], 0, 0, 0);
-            }
-#pragma unroll
-            for (int j = 0; j < NT; ++j) {
-                const int col = wcol0 + j * 32 + l31;
-                if (col < ld_w) {  // columns in [in_f, ld_w) are row padding: written as exact zeros -> whole lines
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) {
-                        const int row = wrow0 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-                        if (row < out_f) {
-                            const float v = acc[j][r];
-                            float* p = out + (int64_t)row * ld_w + col;
-                            if constexpr (NTS)
-                                __builtin_nontemporal_store(v, p);
-                            else
-                                *p = v;
-                            sq += v * v;
-                        }
-                    }
-                }
+            const float* pa = sA + lh * CS + cg * 128 + 4 * l31;
+            float a_nx = pg[0];
+            f32x4 b_nx = *reinterpret_cast<const f32x4*>(pa);
+            for (int q = 0; q < ksteps; ++q) {
+                const float a = a_nx;
+                const f32x4 bv = b_nx;
+                pg += 2 * RS;
+                pa += 2 * CS;
+                a_nx = *pg;  // k-step q+1 (one past the end on the last step: readable padding, never used)
+                b_nx = *reinterpret_cast<const f32x4*>(pa);
+                acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, bv[0], acc[0], 0, 0, 0);
+                acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, bv[1], acc[1], 0, 0, 0);
+                acc[2] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, bv[2], acc[2], 0, 0, 0);
+                acc[3] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, bv[3], acc[3], 0, 0, 0);
+                bsum += a;
             }
         }
-        if (GSb != nullptr && tn == 0 && (int)threadIdx.x < RS && m0 + (int)threadIdx.x < out_f) {
-            float bias_acc = 0.f;
-            for (int r = 0; r < T; ++r) bias_acc += sG[r * RS + threadIdx.x];
-            GSb[(int64_t)b * gs_stride + m0 + threadIdx.x] = bias_acc;
-            sq += bias_acc * bias_acc;
+        // stores: rows >= out_f fall outside the descriptor, columns >= ld_w and dead units get the out-of-range offset
+        // (rows / columns outside the layer hold exact zeros — zero-filled operands — so the squares need no guard)
+        float sq = 0.f;
+        {
+            const auto rsW = make_rsrc(jobs.W[cur.job] + b * gs_stride, live ? (int64_t)out_f * ld_w * 4 : 0);
+            const int col = n0 + cg * 128 + 4 * l31;
+            unsigned soff = col < ld_w ? (unsigned)((m0 + mr * 32 + 4 * lh) * ld_w + col) * 4u : OOB;
+            const unsigned row_bytes = (unsigned)ld_w * 4u;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const f32x4 v = {acc[0][r], acc[1][r], acc[2][r], acc[3][r]};
+                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), rsW, soff, 0, DPK_K1_STORE_AUX);
+                soff += ((r & 3) == 3 ? 5u : 1u) * row_bytes;  // accumulator rows 0 1 2 3 8 9 10 11 ... (OOB stays OOB)
+                sq += v[0] * v[0];
+                sq += v[1] * v[1];
+                sq += v[2] * v[2];
+                sq += v[3] * v[3];
+            }
+        }
+        // bias slice (column-tile 0 only): rows m0 + mr*32 + l31, from the waves of column group 0
+        {
+            bsum += __shfl_xor(bsum, 32, 64);
+            const float* GSb = jobs.Bi[cur.job];
+            const bool has_bias = live && GSb != nullptr && cur.tn == 0;
+            const auto rsB = make_rsrc(GSb + b * gs_stride, has_bias ? (int64_t)out_f * 4 : 0);
+            const bool owner = cg == 0 && lh == 0;
+            __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, bsum), rsB,
+                                                  owner ? (unsigned)(m0 + mr * 32 + l31) * 4u : OOB, 0, 0);
+            if (has_bias && owner) sq += bsum * bsum;
         }
         sq = wave_sum(sq);
         if (lane == 0) red[parity * NW + wave] = sq;
         lds_only_barrier();  // every wave is done with this item's operands; red[parity] is complete
-        if (threadIdx.x == 0) {
+        {
             float tot = 0.f;
 #pragma unroll
             for (int i = 0; i < NW; ++i) tot += red[parity * NW + i];
-            normsq_part[(int64_t)b * part_stride + slot0 + tile] = tot;
+            const auto rsP = make_rsrc(normsq_part + b * part_stride, (int64_t)part_stride * 4);
+            __builtin_amdgcn_raw_buffer_store_b32(
+                __builtin_bit_cast(unsigned, tot), rsP,
+                tid == 0 ? (unsigned)(jobs.slot0[cur.job] + cur.tm * tiles_n + cur.tn) * 4u : OOB, 0, 0);
         }
         parity ^= 1;
-        if (!has_next) break;
-        item = nitem;
-    }
+        more = has_next;
+        cur = nxt;
+    };
+    // The first item is peeled: the loop is then entered only from code that has issued an item's stores behind its
+    // prefetch, which is what lets the compiler count them (vmcnt(N), N >= 17) instead of waiting for everything.
+    do_item();
+    while (more) do_item();
 }
+
+#ifdef DPK_K1_PIPE  // lab builds only: the software-pipelined variant (measured, not adopted: DESIGN.md 8.5)
+#include "../../tools/lab/k1_pipe.inc"
+#endif
 
 inline int dpk_cu_count() {
     static int cached[64] = {0};
@@ -455,8 +515,10 @@ int k1_launch(const float* const* A, const float* const* G, float* const* GSw, f
     const int64_t nblk = ((int64_t)(B + 7) / 8) * 8 * ntile;
     if (nblk * n_jobs > 0x7fffffffLL) return DPK_ERANGE;
     hipStream_t s = (hipStream_t)stream;
-#ifndef DPK_K1_NO_PERSIST
-    if (p.id == 0 && T <= PERSIST_MAX_T) {
+    // Large layers (the 128 x 256 plan) at T <= 48: the persistent wide-unit kernel.  Its 16-byte row stores need a row
+    // stride that is a multiple of 4 floats (the arena's is a multiple of 32: whole 128-byte lines); anything else
+    // takes the launch-per-tile kernel below.
+    if (p.id == 0 && T <= PERSIST_MAX_T && ld_w % 4 == 0) {
         K1Jobs jobs;
         for (int j = 0; j < DPK_K1_MAX_JOBS; ++j) {
             const int q = j < n_jobs ? j : 0;
@@ -465,33 +527,36 @@ int k1_launch(const float* const* A, const float* const* G, float* const* GSw, f
         }
         jobs.n = n_jobs;
         const int Tp = (T + 1) & ~1;
-        const size_t lds = ((size_t)Tp * (128 + 256) + 2 * 8) * sizeof(float);
-        int per_cu = (int)((160 * 1024) / (lds + 512));
-        if (per_cu > 2) per_cu = 2;
-        if (per_cu < 1) per_cu = 1;
-        int64_t want = (int64_t)dpk_cu_count() * per_cu;
-        if (want > nblk * n_jobs) want = nblk * n_jobs;
-        dim3 pgrid((unsigned)((want + 7) / 8 * 8));
-#define DPK_K1_PGO(NG, NA, NTS)                                                                                  \
+#define DPK_K1_PERSIST_GO(KFN, LDS_BYTES)                                                                        \
     do {                                                                                                         \
-        auto kfn = linear_gs_persist_kernel<8, 128, 256, 2, NG, NA, NTS>;                                        \
-        if (lds > 64 * 1024) {                                                                                   \
+        auto kfn = KFN;                                                                                          \
+        if ((LDS_BYTES) > 64 * 1024) {                                                                           \
             hipError_t e_ = hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize,    \
-                                                (int)lds);                                                       \
+                                                (int)(LDS_BYTES));                                               \
             if (e_ != hipSuccess) return (int)e_;                                                                \
         }                                                                                                        \
-        hipLaunchKernelGGL(kfn, pgrid, dim3(512), lds, s, jobs, normsq_part, part_stride, B, T, in_f, out_f,     \
-                           gs_stride, ld_w, ld_g, g_scale, tiles_m, tiles_n);                                          \
+        hipLaunchKernelGGL(kfn, pgrid, dim3(512), (LDS_BYTES), s, jobs, normsq_part, part_stride, B, T, in_f,    \
+                           out_f, gs_stride, ld_w, ld_g, g_scale, tiles_m, tiles_n);                             \
     } while (0)
-        if (T <= 32) {
-            if (nt_store) DPK_K1_PGO(2, 4, true); else DPK_K1_PGO(2, 4, false);
-        } else {
-            if (nt_store) DPK_K1_PGO(3, 6, true); else DPK_K1_PGO(3, 6, false);
+        // one workgroup of 8 waves per CU (128 / 150 registers at T <= 32 / 48; two per CU measured slower)
+        int64_t want = dpk_cu_count();
+        if (want > nblk * n_jobs) want = nblk * n_jobs;
+        const dim3 pgrid((unsigned)((want + 7) / 8 * 8));
+#ifdef DPK_K1_PIPE  // lab builds only
+        if (nt_store && T > 32) {
+            const size_t lds2 = ((size_t)2 * Tp * (128 + 256) + 2 * 256 + 2 * 8) * sizeof(float);
+            DPK_K1_PERSIST_GO(linear_gs_pipe_kernel, lds2);
+            return dpk_launch_status();
         }
-#undef DPK_K1_PGO
+#endif
+        const size_t lds = ((size_t)Tp * (128 + 256) + 2 * 256 + 2 * 8) * sizeof(float);  // + 2 readable pad rows
+        if (T <= 32)
+            DPK_K1_PERSIST_GO((linear_gs_persist_wide_kernel<2, 4>), lds);
+        else
+            DPK_K1_PERSIST_GO((linear_gs_persist_wide_kernel<3, 6>), lds);
+#undef DPK_K1_PERSIST_GO
         return dpk_launch_status();
     }
-#endif
     dim3 grid((unsigned)nblk);
     const bool stream_mode = T <= STREAM_MAX_T;
     const int lds_rows = stream_mode ? ((T + 1) & ~1) : TK;

@@ -384,3 +384,89 @@ def test_argument_errors_launch_nothing(nat):
         nat.linear_grad_sample(A.cpu(), G, nat.FlatView(base, 0, 20), None, part, 0, 1.0)  # CPU tensor
     with pytest.raises(nat.DpkError):
         nat.linear_grad_sample(A, G, nat.FlatView(base, 0, 20), None, part, 1, 1.0)  # slot overflow
+
+
+# ---- K1 on the ARENA layout (what GradSampleArena hands it): windows on 256-byte boundaries, row stride a multiple of
+# 32 floats, rows of awkward width padded — the whole-line path (persistent / software-pipelined kernels).  The shapes
+# above use odd strides on purpose and land on the generic kernels; without these the fast path would only be covered
+# through the engine tests.
+ARENA_SHAPES = [
+    # (B, T, in, out, n_jobs)
+    (9, 48, 250, 1000, 1), (5, 48, 500, 1000, 1), (6, 48, 1000, 250, 1), (11, 48, 250, 250, 1),   # cfg3 layers
+    (70, 24, 512, 512, 1), (33, 24, 256, 128, 6), (17, 24, 400, 200, 6), (40, 24, 208, 208, 1),   # cfg2 / cfg1 layers
+    (3, 1, 130, 33, 1), (4, 31, 300, 260, 2), (2, 47, 129, 129, 3), (300, 12, 160, 40, 1), (1, 48, 512, 97, 1),
+    (13, 32, 384, 70, 1), (5, 33, 640, 64, 1),
+]
+
+
+def _arena_case(nat, B, T, in_f, out_f, nj, bias, seed):
+    from oracle import opacus_ref as O
+    g = torch.Generator().manual_seed(seed)
+    ld = (in_f + 31) // 32 * 32 if (in_f >= 64 and in_f % 32) else in_f
+    win = (ld * out_f + 63) // 64 * 64
+    bwin = (out_f + 63) // 64 * 64
+    row = 64 + nj * (win + bwin) + 64
+    assert row % 32 == 0
+    base = torch.full((B, row), 5.0, device="cuda")
+    assert base.data_ptr() % 256 == 0
+    slots = nat.linear_slots(in_f, out_f)
+    part = torch.full((B, nj * slots + 3), -1.0, device="cuda")
+    As = [torch.randn(B, T, in_f, generator=g) for _ in range(nj)]
+    Gs = [torch.randn(B, T, out_f, generator=g) * 0.01 for _ in range(nj)]
+    jobs = []
+    for j in range(nj):
+        off = 64 + j * (win + bwin)
+        jobs.append((As[j].cuda(), Gs[j].cuda(), nat.FlatView(base, off, ld * out_f),
+                     nat.FlatView(base, off + win, out_f) if bias else None, 1 + j * slots))
+    if nj == 1:
+        a, gg, vw, vb, s0 = jobs[0]
+        nat.linear_grad_sample(a, gg, vw, vb, part, s0, float(B), ld_w=ld)
+    else:
+        nat.linear_grad_sample_group(jobs, part, float(B), ld_w=ld)
+    out, p = base.cpu(), part.cpu()
+    touched = torch.zeros(row, dtype=torch.bool)
+    for j in range(nj):
+        off = 64 + j * (win + bwin)
+        gw_ref, gb_ref = O.linear_grad_sample(As[j], Gs[j] * float(B), True)
+        w = out[:, off:off + ld * out_f].reshape(B, out_f, ld)
+        assert rel_err(w[:, :, :in_f].numpy(), gw_ref.numpy()) < TOL, (j, "weight")
+        assert (w[:, :, in_f:] == 0).all(), "row padding must be exact zeros"
+        # row-wise too: a sample with a small gradient must not hide behind one with a large gradient
+        num = (w[:, :, :in_f] - gw_ref).abs().amax((1, 2))
+        assert float((num / gw_ref.abs().amax((1, 2)).clamp_min(1e-30)).max()) < TOL
+        ref_sq = (gw_ref.double() ** 2).sum((1, 2))
+        touched[off:off + ld * out_f] = True
+        if bias:
+            assert rel_err(out[:, off + win:off + win + out_f].numpy(), gb_ref.numpy()) < TOL, (j, "bias")
+            ref_sq = ref_sq + (gb_ref.double() ** 2).sum(1)
+            touched[off + win:off + win + out_f] = True
+        got_sq = p[:, 1 + j * slots:1 + (j + 1) * slots].double().sum(1)
+        assert rel_err(got_sq.numpy(), ref_sq.numpy()) < TOL, (j, "normsq")
+    assert (out[:, ~touched] == 5.0).all(), "wrote outside the layer's windows"
+    assert (p[:, 0] == -1).all() and (p[:, 1 + nj * slots:] == -1).all()
+
+
+@pytest.mark.parametrize("B,T,in_f,out_f,nj", ARENA_SHAPES)
+@pytest.mark.parametrize("bias", [True, False])
+def test_linear_grad_sample_arena_layout(nat, B, T, in_f, out_f, nj, bias):
+    _arena_case(nat, B, T, in_f, out_f, nj, bias, seed=B * 1000 + T)
+
+
+def test_linear_grad_sample_arena_layout_many_items_is_deterministic(nat):
+    """Far more (sample, tile) items than workgroups: every workgroup's pipeline runs for many stages; twice, bit for bit."""
+    B, T, in_f, out_f = 700, 48, 250, 500
+    ld, win = 256, 256 * 500
+    g = torch.Generator().manual_seed(1)
+    A = torch.randn(B, T, in_f, generator=g).cuda()
+    G = torch.randn(B, T, out_f, generator=g).cuda()
+    outs = []
+    for _ in range(2):
+        base = torch.zeros(B, win + 512, device="cuda")
+        part = torch.zeros(B, nat.linear_slots(in_f, out_f), device="cuda")
+        nat.linear_grad_sample(A, G, nat.FlatView(base, 0, win), nat.FlatView(base, win, out_f), part, 0, float(B), ld_w=ld)
+        outs.append((base.cpu(), part.cpu()))
+    assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
+    ref = torch.einsum("bto,bti->boi", G.double() * B, A.double()).cpu()
+    w = outs[0][0][:, :win].reshape(B, out_f, ld)[:, :, :in_f].double()
+    err = (w - ref).abs().amax((1, 2)) / ref.abs().amax((1, 2))
+    assert float(err.max()) < TOL
