@@ -64,15 +64,14 @@ def main(argv=None):
     n_nums = data.shape[2] - args.n_bins - args.n_cats
     from dp_timeautodiff_amd.train import train_dp_autoencoder
     t0 = time.time()
+    info = {"n_bins": args.n_bins, "n_cats": args.n_cats, "n_nums": n_nums, "cards": args.cards}
     out = train_dp_autoencoder(
-        data, n_bins=args.n_bins, n_cats=args.n_cats, n_nums=n_nums, cards=args.cards, channels=args.channels,
-        hidden_size=args.hidden_size, num_layers=args.num_layers, lr=args.lr, weight_decay=args.weight_decay,
-        n_epochs=args.n_epochs, batch_size=args.batch_size, min_beta=args.min_beta, max_beta=args.max_beta,
-        emb_dim=args.emb_dim, time_dim=args.time_dim, lat_dim=args.lat_dim, device=dev, epsilon=args.epsilon,
-        delta=args.delta, max_grad_norm=args.max_grad_norm, save_path=args.save_path, load_path=args.load_path,
+        info, data, args.channels, args.hidden_size, args.num_layers, args.lr, args.weight_decay, args.n_epochs,
+        args.batch_size, 1, args.min_beta, args.max_beta, args.emb_dim, args.time_dim, args.lat_dim, dev, args.epsilon,
+        args.delta, args.max_grad_norm, args.save_path, args.load_path,
         max_physical_batch_size=args.max_physical_batch_size, accountant=args.accountant,
         use_graph=not args.no_graph, tune_gemms=args.tune_gemms, noise_seed=args.seed, sampler_seed=args.seed)
-    print(json.dumps({"epsilon_spent": out[-1], "target_epsilon": args.epsilon, "seconds": round(time.time() - t0, 2),
+    print(json.dumps({"epsilon_spent": out[7], "target_epsilon": args.epsilon, "seconds": round(time.time() - t0, 2),
                       "samples": int(data.shape[0]), "epochs": args.n_epochs}))
 
 

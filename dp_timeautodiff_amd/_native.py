@@ -52,7 +52,7 @@ EXPORTS = {
     "dpk_lstm_pack_forward": (c_int, [c_void_p, c_void_p, c_int, c_int, c_void_p]),
     "dpk_lstm_pack_backward": (c_int, [c_void_p, c_void_p, c_int, c_int, c_void_p]),
     "dpk_lstm_forward": (c_int, [c_void_p] * 9 + [c_int] * 5 + [c_void_p]),
-    "dpk_lstm_backward": (c_int, [c_void_p] * 8 + [c_int] * 6 + [c_void_p]),
+    "dpk_lstm_backward": (c_int, [c_void_p] * 9 + [c_int] * 6 + [c_void_p]),
     "dpk_gru_pack_floats": (c_int64, [c_int, c_int]),
     "dpk_gru_pack_forward": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p]),
     "dpk_gru_pack_backward": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_int, c_int, c_void_p]),
@@ -503,8 +503,9 @@ def lstm_forward(xgs, h0s, c0s, bhhs, P, reverse_mask: int):
     return out, gates, C, Hprev
 
 
-def lstm_backward(douts, c0s, gates, C, Pt, reverse_mask: int, want_d0: bool):
+def lstm_backward(douts, c0s, gates, C, Pt, reverse_mask: int, want_d0: bool, dcTs=None):
     """douts: G tensors [B,T,H] (None = zeros), all dense or all column blocks of one [B,T,W] gradient buffer.
+    dcTs: None or G tensors [B,H] = gradient of each recurrence's final cell state (None entries = zeros).
     Returns dpre [G,B,T,4H] and (dh0, dc0) [G,B,H] or (None, None)."""
     _req(C, "C"); _req(gates, "gates"); _req(Pt, "Pt")
     if C.dim() != 4 or not C.is_contiguous():
@@ -526,10 +527,13 @@ def lstm_backward(douts, c0s, gates, C, Pt, reverse_mask: int, want_d0: bool):
             _req(d, f"dout[{i}]")
             da[i] = d.data_ptr()
     ca = None if c0s is None else _ptr_array(c0s, "c0", (B, H))
+    if dcTs is not None and len(dcTs) != G:
+        raise DpkError("lstm_backward: dcT must have one entry per recurrence")
+    dca = None if dcTs is None or all(d is None for d in dcTs) else _ptr_array(dcTs, "dcT", (B, H), allow_none=True)
     dpre = torch.empty_like(gates)
     dh0 = torch.empty(G, B, H, device=C.device, dtype=torch.float32) if want_d0 else None
     dc0 = torch.empty(G, B, H, device=C.device, dtype=torch.float32) if want_d0 else None
-    rc = load().dpk_lstm_backward(da, ca, _ptr(gates), _ptr(C), _ptr(Pt), _ptr(dpre), _ptr(dh0), _ptr(dc0),
+    rc = load().dpk_lstm_backward(da, dca, ca, _ptr(gates), _ptr(C), _ptr(Pt), _ptr(dpre), _ptr(dh0), _ptr(dc0),
                                   int(reverse_mask), B, T, H, G, int(ld_dout), _stream())
     _check(rc, "dpk_lstm_backward")
     return dpre, dh0, dc0

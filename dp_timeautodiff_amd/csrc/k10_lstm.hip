@@ -221,7 +221,7 @@ __global__ void __launch_bounds__(LNW * 64) lstm_fwd_kernel(GPtrs xgs, GPtrs h0s
 }
 
 template <int TPW>
-__global__ void __launch_bounds__(LNW * 64) lstm_bwd_kernel(GPtrs douts, GPtrs c0s, const float* __restrict__ gates,
+__global__ void __launch_bounds__(LNW * 64) lstm_bwd_kernel(GPtrs douts, GPtrs dcTs, GPtrs c0s, const float* __restrict__ gates,
                                                             const float* __restrict__ C,
                                                             const f32x4* __restrict__ Pt, float* __restrict__ dpre,
                                                             float* __restrict__ dh0, float* __restrict__ dc0,
@@ -239,6 +239,7 @@ __global__ void __launch_bounds__(LNW * 64) lstm_bwd_kernel(GPtrs douts, GPtrs c
     const bool rev = (reverse_mask >> gi) & 1;
     const float* __restrict__ dout = douts.p[gi];
     const float* __restrict__ c0 = c0s.p[gi];
+    const float* __restrict__ dcT = dcTs.p[gi];  // dL/dc_n of this recurrence: seeds the carried dc (nullable)
     {
         const int64_t g = gi, gx = g * B * T * H;
         gates += 4 * gx; C += gx; dpre += 4 * gx;
@@ -253,7 +254,12 @@ __global__ void __launch_bounds__(LNW * 64) lstm_bwd_kernel(GPtrs douts, GPtrs c
     f32x4 dhc[TPW], dcc[TPW];
     f32x4 p_do[TPW], p_g[TPW][4], p_c[TPW], p_cp[TPW];
 #pragma unroll
-    for (int i = 0; i < TPW; ++i) dhc[i] = dcc[i] = zero4;
+    for (int i = 0; i < TPW; ++i) {
+        dhc[i] = dcc[i] = zero4;
+        const int o = (wave + LNW * i) * 16 + q * 4;
+        const int nv = min(4, H - o);
+        if (dcT && nv > 0 && bvalid) dcc[i] = ldv(dcT + (int64_t)b * H + o, nv);
+    }
     // processing order of the forward pass was s = 0..T-1 (t = s, or T-1-s when reversed); walk it backwards
     auto load_step = [&](int s) {
         const int t = rev ? T - 1 - s : s;
@@ -422,7 +428,8 @@ extern "C" int dpk_lstm_forward(const float* const* xg, const float* const* h0, 
     return dpk_launch_status();
 }
 
-extern "C" int dpk_lstm_backward(const float* const* dout, const float* const* c0, const float* gates,
+extern "C" int dpk_lstm_backward(const float* const* dout, const float* const* dcT, const float* const* c0,
+                                 const float* gates,
                                  const float* C, const float* Pt, float* dpre, float* dh0, float* dc0,
                                  int reverse_mask, int B, int T, int H, int G, int ld_dout, void* stream) {
     if (!dout || !gates || !C || !Pt || !dpre || ld_dout < H) return DPK_EINVAL;
@@ -430,9 +437,10 @@ extern "C" int dpk_lstm_backward(const float* const* dout, const float* const* c
     const void* ptrs[] = {gates, C, Pt, dpre, dh0, dc0};
     for (const void* p : ptrs)
         if (p && !dpk_aligned16(p)) return DPK_EALIGN;
-    GPtrs ds{}, cs{};
+    GPtrs ds{}, dcs{}, cs{};
     for (int g = 0; g < G; ++g) {
         ds.p[g] = dout[g];
+        dcs.p[g] = dcT ? dcT[g] : nullptr;
         cs.p[g] = c0 ? c0[g] : nullptr;
     }
     const size_t lds = (size_t)((4 * H + 15) / 16) * 16 * GBT * sizeof(float);
@@ -446,7 +454,7 @@ extern "C" int dpk_lstm_backward(const float* const* dout, const float* const* c
                                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);              \
             if (e_ != hipSuccess) return (int)e_;                                                                   \
         }                                                                                                           \
-        hipLaunchKernelGGL((lstm_bwd_kernel<TPW>), grid, dim3(LNW * 64), lds, s, ds, cs, gates, C,                  \
+        hipLaunchKernelGGL((lstm_bwd_kernel<TPW>), grid, dim3(LNW * 64), lds, s, ds, dcs, cs, gates, C,             \
                            (const f32x4*)Pt, dpre, dh0, dc0, reverse_mask, B, T, H, ld_dout);                       \
     } while (0)
     if (lstm_tpw(H) == 1) DPK_LSTM_B(1);

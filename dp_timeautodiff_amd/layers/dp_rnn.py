@@ -208,8 +208,9 @@ class _LSTMRecurrence(torch.autograd.Function):
         ctx.has_bias = bhhs is not None
         ctx.save_for_backward(gates, C, Hprev, *whh, *(c0s or []))
         T = out.shape[1]
-        c_n = tuple(C[g, :, 0 if (reverse_mask >> g) & 1 else T - 1] for g in range(G))
-        ctx.mark_non_differentiable(*c_n)
+        # final cell states: returned as their own (differentiable) outputs — a loss that reads c_n (a state handed on
+        # to the next segment) gets its gradient back through the kernel's dcT input
+        c_n = tuple(C[g, :, 0 if (reverse_mask >> g) & 1 else T - 1].clone() for g in range(G))
         return (out,) + c_n
 
     @staticmethod
@@ -226,8 +227,9 @@ class _LSTMRecurrence(torch.autograd.Function):
             dcat = dcat.contiguous()
         douts = [None if dcat is None else dcat[..., g * H:(g + 1) * H] for g in range(G)]  # column blocks, ld = G*H
         Pt = _native.lstm_pack_backward(list(whh), H)
+        dcTs = [None if d is None else d.contiguous() for d in grads_out[1:1 + G]]
         dpre, dh0, dc0 = _native.lstm_backward(douts, list(c0s) if c0s else None, gates, C, Pt, ctx.reverse_mask,
-                                               want_d0)
+                                               want_d0, dcTs=dcTs)
         grads = []
         for g in range(G):
             cell = ctx.cells[g]

@@ -38,10 +38,11 @@ class PrivacyEngine:
         self.dataset = None  # only used to detect switching to a different dataset
         self.fuse_recurrence = True  # make_private(fuse_recurrence=False) keeps the hooked T-call protocol
         if self.secure_mode:
-            # the Philox stream is keyed from os.urandom either way; a CSPRNG-backed torch generator
-            # (torchcsprng) is not available in this image
-            warnings.warn("secure_mode: DP noise is drawn from a Philox4x32-10 stream seeded from os.urandom; "
-                          "Poisson sampling uses torch's default generator")
+            # Opacus' secure mode needs a cryptographically safe generator (torchcsprng) for sampling and noise, and
+            # draws the noise as a sum of four samples; this engine's noise is Philox4x32-10 (not a CSPRNG) and there is
+            # no CSPRNG in this image.  Refuse rather than hand back the ordinary path under that name.
+            raise NotImplementedError("secure_mode=True is not supported: DP noise and Poisson sampling come from "
+                                      "Philox4x32-10 counter streams, which are not cryptographically secure")
 
     # ---- internals ----------------------------------------------------------------------------------
     def _prepare_optimizer(self, *, optimizer: optim.Optimizer, noise_multiplier: float, max_grad_norm,

@@ -21,7 +21,7 @@ from typing import Optional
 
 import torch
 
-from . import models
+from . import data_types, models
 from .batch_memory_manager import BatchMemoryManager
 from .data_loader import DevicePoissonLoader
 from .graphed import GraphedDPStep
@@ -29,13 +29,25 @@ from .privacy_engine import PrivacyEngine
 from .validators import ModuleValidator
 
 
-def train_dp_autoencoder(processed_data: torch.Tensor, *, n_bins: int, n_cats: int, n_nums: int, cards, channels: int,
-                         hidden_size: int, num_layers: int, lr: float, weight_decay: float, n_epochs: int,
-                         batch_size: int, min_beta: float, max_beta: float, emb_dim: int, time_dim: int, lat_dim: int,
-                         device, epsilon: float, delta: float = 1e-5, max_grad_norm: float = 1.0,
-                         save_path: Optional[str] = None, load_path: Optional[str] = None, lambd: float = 0.7,
-                         max_physical_batch_size: int = 128, accountant: str = "prv", use_graph: bool = True,
-                         tune_gemms: bool = False, noise_seed: Optional[int] = None, sampler_seed: Optional[int] = None, log=print):
+def train_dp_autoencoder(real_df, processed_data: torch.Tensor, channels: int, hidden_size: int, num_layers: int,
+                         lr: float, weight_decay: float, n_epochs: int, batch_size: int, threshold, min_beta: float,
+                         max_beta: float, emb_dim: int, time_dim: int, lat_dim: int, device, epsilon: float,
+                         delta: float = 1e-5, max_grad_norm: float = 1.0, save_path: Optional[str] = None,
+                         load_path: Optional[str] = None, *, lambd: float = 0.7, max_physical_batch_size: int = 128,
+                         accountant: str = "prv", use_graph: bool = True, tune_gemms: bool = False,
+                         noise_seed: Optional[int] = None, sampler_seed: Optional[int] = None, log=print):
+    """Same positional arguments, defaults and 8-tuple as the reference's function (timeautoencoder.py:603-625, :786):
+
+        (ae, latent_features.detach(), output, losses, recons_loss, mu_z, logvar_z, epsilon)
+
+    so `run_dp_experiments` (timeautodiff_run.py:315-336: `[0]`, `[1]`, `[7]`) can call it as is.  `real_df` is the
+    reference's DataFrame (typed by data_types.datatype_info, its parser's rule), a fitted parser, or the
+    {n_bins, n_cats, n_nums, cards} dict.  `losses` / `recons_loss` hold one value per epoch (the reference creates the
+    lists and never appends, :688-690, :775-777); `mu_z` / `logvar_z` are the encoder outputs of the final full-data
+    forward (the reference returns whatever the last training batch left in those names).  Everything after `load_path`
+    is keyword-only and belongs to this engine."""
+    info = data_types.resolve(real_df, threshold)
+    n_bins, n_cats, n_nums, cards = info["n_bins"], info["n_cats"], info["n_nums"], info["cards"]
     device = torch.device(device)
     if tune_gemms and device.type == "cuda":
         # per-shape hipBLASLt/rocBLAS solution for the model's own GEMMs (+3 % at cfg2); the choice is timing-based, so
@@ -88,6 +100,7 @@ def train_dp_autoencoder(processed_data: torch.Tensor, *, n_bins: int, n_cats: i
         ae.train()
         graphed = GraphedDPStep(ae, optimizer_ae, loss_fn, warmup=steps_done_by_capture, loader=train_loader).capture()
     eps_now, loss_val = 0.0, float("nan")
+    losses, recons_loss = [], []
     for epoch in range(start_epoch, n_epochs):
         ae.train()
         epoch_loss = torch.zeros((), device=device)
@@ -111,7 +124,8 @@ def train_dp_autoencoder(processed_data: torch.Tensor, *, n_bins: int, n_cats: i
                         num_batches += 1
         eps_now = privacy_engine.get_epsilon(delta)
         loss_val = float(loss_t.detach())
-        log(f"Epoch {epoch + 1}/{n_epochs} - Avg Loss: {float(epoch_loss) / max(num_batches, 1):.4f} - eps: {eps_now:.2f}")
+        losses.append(float(epoch_loss) / max(num_batches, 1))
+        log(f"Epoch {epoch + 1}/{n_epochs} - Avg Loss: {losses[-1]:.4f} - eps: {eps_now:.2f}")
         if loss_val < best_train_loss:
             best_train_loss, patience = loss_val, 0
         else:
@@ -131,4 +145,6 @@ def train_dp_autoencoder(processed_data: torch.Tensor, *, n_bins: int, n_cats: i
     ae.eval()
     with torch.no_grad():
         output, latent_features, mu_z, logvar_z = ae(processed_data.to(device))
-    return ae, latent_features.detach(), output, mu_z, logvar_z, eps_now
+        recons_loss.append(float(sum(l for l in models.auto_loss(processed_data.to(device), output, n_bins, n_nums,
+                                                                  n_cats, 0.0, cards))))
+    return ae, latent_features.detach(), output, losses, recons_loss, mu_z, logvar_z, eps_now

@@ -253,6 +253,8 @@ int dpk_poisson_sample(uint64_t seed, uint64_t offset, const uint64_t* offset_de
  * backward writes dpre [G,B,T,4H] = dL/d(pre-activation) — both dL/dxg and the `G` operand of the ih and hh
  *   per-sample-gradient contractions — and, if non-NULL, dh0 / dc0 [G,B,H].  dout[g]: [B,T,H] rows of stride ld_dout
  *   (H for a dense tensor, G*H for column block g of the concatenated output's gradient; NULL entry = zeros).
+ *   dcT: NULL or per-recurrence [B,H] = dL/dc_n, the gradient of the final cell state (a loss that reads c_n, e.g. a
+ *   state handed to the next segment); NULL entry = zeros.  (dL/dh_n arrives through dout: h_n is a row of out.)
  * H <= 256, any H >= 1 (rows that are not 16-byte aligned are accessed in smaller pieces).
  */
 int dpk_lstm_pack_forward(const float* const* Whh, float* P, int H, int G, void* stream);
@@ -260,7 +262,7 @@ int dpk_lstm_pack_backward(const float* const* Whh, float* Pt, int H, int G, voi
 int dpk_lstm_forward(const float* const* xg, const float* const* h0, const float* const* c0,
                      const float* const* bhh, const float* P, float* out, float* gates, float* C,
                      float* Hprev, int reverse_mask, int B, int T, int H, int G, void* stream);
-int dpk_lstm_backward(const float* const* dout, const float* const* c0, const float* gates,
+int dpk_lstm_backward(const float* const* dout, const float* const* dcT, const float* const* c0, const float* gates,
                       const float* C, const float* Pt, float* dpre, float* dh0, float* dc0,
                       int reverse_mask, int B, int T, int H, int G, int ld_dout, void* stream);
 

@@ -32,16 +32,17 @@ def test_fused_dplstm_matches_nn_lstm(B, T, I, H, L, bi, with_state, batch_first
     oshape = (B, T, D * H) if batch_first else (T, B, D * H)
     w = torch.randn(*oshape, dtype=torch.float64)
     wh = torch.randn(L * D, B, H, dtype=torch.float64)
+    wc = torch.randn(L * D, B, H, dtype=torch.float64)  # the loss also reads c_n (its gradient was dropped)
 
     xr = x.clone().requires_grad_(True)
     str_ = tuple(s.clone().requires_grad_(True) for s in st) if st else None
     o_r, (h_r, c_r) = ref(xr, str_)
-    ((o_r * w).sum() + (h_r * wh).sum()).backward()
+    ((o_r * w).sum() + (h_r * wh).sum() + (c_r * wc).sum()).backward()
 
     xg = x.float().cuda().requires_grad_(True)
     stg = tuple(s.float().cuda().requires_grad_(True) for s in st) if st else None
     o_g, (h_g, c_g) = dp(xg, stg)
-    ((o_g * w.float().cuda()).sum() + (h_g * wh.float().cuda()).sum()).backward()
+    ((o_g * w.float().cuda()).sum() + (h_g * wh.float().cuda()).sum() + (c_g * wc.float().cuda()).sum()).backward()
     torch.cuda.synchronize()
 
     for got, want in ((o_g, o_r), (h_g, h_r), (c_g, c_r), (xg.grad, xr.grad)):
