@@ -27,7 +27,7 @@ import torch
 import torch.nn as nn
 
 from . import _native
-from .layers import RNNLinear
+from .layers import RNNLinear, SequenceBias
 from .layers.fused_gru import FusedLinearCellGRU
 
 ARENA_ALIGN = 64  # floats: every parameter window starts on a 256-byte boundary
@@ -177,6 +177,8 @@ def _kind_of(m: nn.Module) -> Optional[str]:
         return "embedding"
     if t is nn.LayerNorm:
         return "layernorm"
+    if t is SequenceBias:
+        return "seqbias"
     return None
 
 
@@ -246,6 +248,8 @@ class GradSampleModule(nn.Module):
                 continue
             if kind == "linear":
                 n = _native.linear_slots(sub.in_features, sub.out_features)
+            elif kind == "seqbias":
+                n = _native.linear_slots(1, sub.bias.numel())
             elif kind == "layernorm":
                 if len(sub.normalized_shape) != 1 or not sub.elementwise_affine:
                     raise NotImplementedError(f"{name}: only affine LayerNorm over the last dim is supported")
@@ -436,6 +440,12 @@ class GradSampleModule(nn.Module):
         layer.pairs = []
         m = layer.module
         bf = True if isinstance(m, RNNLinear) else None  # DP RNN cells are always called batch-major
+        if layer.kind == "seqbias":
+            # the bias is the LAST token of the output: its per-sample gradient is that token's backprop.  Written as
+            # a Linear contraction with a unit activation (in = 1), so K1 does the copy, the scaling and the norm.
+            G = torch.stack([(g[:, -1] if m.batch_first else g[-1]) for _, g in pairs], 1).contiguous()
+            self._emit(layer, G.new_ones(G.shape[0], G.shape[1], 1), G)
+            return
         if layer.kind == "embedding":
             A = self._stack([p[0] for p in pairs], 0).to(torch.int64)
         else:
@@ -524,6 +534,8 @@ class GradSampleModule(nn.Module):
             vb = arena.flat(m.bias, row0) if m.bias is not None else None
             _native.linear_grad_sample(A, G, arena.flat(m.weight, row0), vb, part, layer.slot0, g_scale,
                                        ld_w=arena.window(m.weight).ld)
+        elif layer.kind == "seqbias":
+            _native.linear_grad_sample(A, G, arena.flat(m.bias, row0), None, part, layer.slot0, g_scale, ld_w=1)
         elif layer.kind == "embedding":
             _native.embedding_grad_sample(A, G, arena.flat(m.weight, row0), m.num_embeddings, part, layer.slot0,
                                           g_scale)

@@ -11,6 +11,8 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
+from .dp_rnn import RNNLinear
+
 
 class SequenceBias(nn.Module):
     """Adds one learned bias token to a [T, B, E] sequence (add_bias_kv of nn.MultiheadAttention)."""
@@ -33,8 +35,6 @@ class DPMultiheadAttention(nn.Module):
     def __init__(self, embed_dim, num_heads, dropout=0.0, bias=True, add_bias_kv=False, add_zero_attn=False,
                  kdim=None, vdim=None, batch_first=False, device=None, dtype=None):
         super().__init__()
-        if add_bias_kv or add_zero_attn:
-            raise NotImplementedError("add_bias_kv / add_zero_attn are not supported")
         self.embed_dim = embed_dim
         self.kdim = kdim if kdim is not None else embed_dim
         self.vdim = vdim if vdim is not None else embed_dim
@@ -44,11 +44,18 @@ class DPMultiheadAttention(nn.Module):
         self.head_dim = embed_dim // num_heads
         if self.head_dim * num_heads != embed_dim:
             raise ValueError("embed_dim must be divisible by num_heads")
-        self.qlinear = nn.Linear(embed_dim, embed_dim, bias=bias)
-        self.klinear = nn.Linear(self.kdim, embed_dim, bias=bias)
-        self.vlinear = nn.Linear(self.vdim, embed_dim, bias=bias)
-        self.out_proj = nn.Linear(embed_dim, embed_dim, bias=bias)
+        # RNNLinear: "always called batch-major" for the grad-sample hooks, whatever layout the wrapped model uses
+        # (forward transposes [T,B,E] inputs first, so these four never see a sequence-first tensor)
+        self.qlinear = RNNLinear(embed_dim, embed_dim, bias=bias)
+        self.klinear = RNNLinear(self.kdim, embed_dim, bias=bias)
+        self.vlinear = RNNLinear(self.vdim, embed_dim, bias=bias)
+        self.out_proj = RNNLinear(embed_dim, embed_dim, bias=bias)
         self.dropout_layer = nn.Dropout(dropout)
+        self.add_bias_kv = add_bias_kv
+        self.add_zero_attn = add_zero_attn
+        if add_bias_kv:  # nn.MultiheadAttention's bias_k / bias_v: one learned token appended to k and to v
+            self.seq_bias_k = SequenceBias(embed_dim, batch_first=True)
+            self.seq_bias_v = SequenceBias(embed_dim, batch_first=True)
 
     def load_from_mha(self, mha: nn.MultiheadAttention):
         """Copy weights from an nn.MultiheadAttention (packed in_proj or separate q/k/v)."""
@@ -69,6 +76,9 @@ class DPMultiheadAttention(nn.Module):
             self.out_proj.weight.copy_(mha.out_proj.weight)
             if mha.out_proj.bias is not None:
                 self.out_proj.bias.copy_(mha.out_proj.bias)
+            if self.add_bias_kv:
+                self.seq_bias_k.bias.copy_(mha.bias_k.reshape(-1))
+                self.seq_bias_v.bias.copy_(mha.bias_v.reshape(-1))
 
     def forward(self, query, key, value, key_padding_mask=None, need_weights=True, attn_mask=None,
                 is_causal=False):
@@ -78,8 +88,22 @@ class DPMultiheadAttention(nn.Module):
         Tk = key.shape[1]
         H, Dh = self.num_heads, self.head_dim
         q = self.qlinear(query).view(B, Tq, H, Dh).transpose(1, 2)
-        k = self.klinear(key).view(B, Tk, H, Dh).transpose(1, 2)
-        v = self.vlinear(value).view(B, Tk, H, Dh).transpose(1, 2)
+        k, v = self.klinear(key), self.vlinear(value)
+        extra = 0
+        if self.add_bias_kv:  # appended after the projections, as nn.MultiheadAttention does
+            k, v = self.seq_bias_k(k), self.seq_bias_v(v)
+            extra += 1
+        if self.add_zero_attn:
+            k, v = (torch.cat([t, t.new_zeros(B, 1, E)], 1) for t in (k, v))
+            extra += 1
+        if extra:  # the appended tokens are visible to every query and never padding
+            Tk += extra
+            if attn_mask is not None:
+                attn_mask = F.pad(attn_mask, (0, extra))
+            if key_padding_mask is not None:
+                key_padding_mask = F.pad(key_padding_mask, (0, extra))
+        k = k.view(B, Tk, H, Dh).transpose(1, 2)
+        v = v.view(B, Tk, H, Dh).transpose(1, 2)
         scores = torch.matmul(q * (Dh ** -0.5), k.transpose(-2, -1))
         if attn_mask is not None:
             if attn_mask.dtype == torch.bool:

@@ -18,7 +18,7 @@ from typing import List
 import torch
 import torch.nn as nn
 
-from .layers import DPGRU, DPLSTM, DPMultiheadAttention, RNNLinear
+from .layers import DPGRU, DPLSTM, DPMultiheadAttention, RNNLinear, SequenceBias
 
 
 class UnsupportedModuleError(ValueError):
@@ -34,7 +34,7 @@ class ShouldReplaceModuleError(UnsupportedModuleError):
 
 
 # leaf types whose parameters are served by a HIP per-sample-gradient kernel
-SUPPORTED_PARAM_MODULES = (nn.Linear, RNNLinear, nn.Embedding, nn.LayerNorm)
+SUPPORTED_PARAM_MODULES = (nn.Linear, RNNLinear, nn.Embedding, nn.LayerNorm, SequenceBias)
 _BATCHNORM = (nn.BatchNorm1d, nn.BatchNorm2d, nn.BatchNorm3d, nn.SyncBatchNorm)
 _INSTANCENORM = (nn.InstanceNorm1d, nn.InstanceNorm2d, nn.InstanceNorm3d)
 
@@ -84,7 +84,7 @@ class ModuleValidator:
                     errors.append(UnsupportedModuleError(
                         f"{name or 'Main'}: {type(sub).__name__} owns trainable parameters but has no "
                         "per-sample-gradient kernel in this build (supported: Linear, Embedding, LayerNorm, "
-                        "DPLSTM/DPGRU cells, DPMultiheadAttention)."))
+                        "DPLSTM/DPGRU cells, DPMultiheadAttention, SequenceBias)."))
         if strict and len(errors) > 0:
             raise UnsupportedModuleError(errors)
         return errors
@@ -124,7 +124,8 @@ class ModuleValidator:
             return new
         if isinstance(sub, nn.MultiheadAttention):
             new = DPMultiheadAttention(sub.embed_dim, sub.num_heads, dropout=sub.dropout,
-                                       bias=sub.in_proj_bias is not None, kdim=sub.kdim, vdim=sub.vdim,
+                                       bias=sub.in_proj_bias is not None, add_bias_kv=sub.bias_k is not None,
+                                       add_zero_attn=sub.add_zero_attn, kdim=sub.kdim, vdim=sub.vdim,
                                        batch_first=sub.batch_first)
             new.load_from_mha(sub)
             return new

@@ -60,3 +60,18 @@ def rel_err(a, b):
     b = np.asarray(b, dtype=np.float64)
     denom = max(np.abs(b).max(), 1e-30)
     return float(np.abs(a - b).max() / denom)
+
+
+def row_err(a, b):
+    """max over samples of max |a[s]-b[s]| / max |b[s]|: each sample's row judged on its own scale, so a sample with a
+    large gradient cannot mask an error in a sample with a small one.  Rows of an all-zero reference are skipped
+    (a parameter a sample does not touch, e.g. unused embedding rows) after checking they are zero in `a` too."""
+    a = np.asarray(a, dtype=np.float64).reshape(len(a), -1)
+    b = np.asarray(b, dtype=np.float64).reshape(len(b), -1)
+    assert a.shape == b.shape
+    scale = np.abs(b).max(1)
+    live = scale > 0
+    assert not np.abs(a[~live]).any()
+    if not live.any():
+        return 0.0
+    return float((np.abs(a - b).max(1)[live] / scale[live]).max())
