@@ -1,27 +1,35 @@
-// K1 — per-sample gradient of a Linear layer as a batched fp32 MFMA GEMM with K = T.
+// K1 — per-sample gradient of a Linear layer as a batched GEMM with K = T (one GEMM per sample).
 //
 //   GSw[b,o,i] = sum_t (g_scale*G[b,t,o]) * A[b,t,i]       GSb[b,o] = sum_t g_scale*G[b,t,o]
 //
-// "Operand-resident" structure (round-1 lab result, tools/lab/k1_lab.hip): the kernel is bound by HBM
-// *writes* at the reference's T=24 (AI = T/2 flop per byte), and on CDNA4 a CU's vector-memory pipe is
-// in order across its waves — operand loads queue behind other waves' pending stores.  So the load
-// volume per output byte is what has to shrink: one workgroup (8 waves) stages a [TK x 128] slice of G and
-// a [TK x 256] slice of A of ONE sample in LDS (operand bytes per output byte = T*(1/128+1/256) = 0.28
-// instead of 0.56 for a 64x128 tile), then every wave runs the 12 MFMAs (v_mfma_f32_32x32x2_f32, fed by
-// unit-stride conflict-free ds_read_b32) of its 32x64 micro-tiles and streams the accumulators out.
-// The accumulator layout (col = lane&31, rows in registers) makes every store instruction two full
-// 128-byte row segments; when the row stride is a multiple of 128 B those are whole cache lines and are
-// written non-temporally (the arena is read back exactly once, by K7, long after it left the caches):
-// 3.0 -> 5.1 TB/s on a [512 x 512] layer at B=1024.
-// T > 32 is handled by K-chunks of 32 steps with the accumulators kept in registers across chunks.
-// f32-in MFMA is an exact k-ordered fmaf chain and all reductions have a fixed order: deterministic.
-// The epilogue emits sum(GS^2) of the tile (+ the bias slice in column-tile 0) as ONE float per
-// (sample, tile), so the norm pass of DPOptimizer.clip_and_accumulate never re-reads the gradient.
+// The output (B x out x in floats, written once, read back once by K7) is what bounds the kernel: AI = T/2 flop per
+// byte.  Three kernels, chosen by k1_launch():
 //
-// Grid: 1-D, XCD-aware: blocks id and id+8 share an XCD (round-robin dispatch), so all tiles of sample b get
-// ids congruent to b mod 8 and consecutive in id/8 — a sample's A/G slices are then fetched into ONE XCD's
-// L2 and re-read there by its other tiles.  (Placement is used for speed only; results do not depend on it.)
+//   linear_gs_kernel               launch-per-tile, fp32 MFMA; small layers (in <= 128 or out <= 32) and arena rows
+//                                  whose stride is not a multiple of 4 floats.  One workgroup stages a [T x RS] slice
+//                                  of G and a [T x CS] slice of A of ONE sample in LDS and streams the tile out.
+//   linear_gs_persist_wide_kernel  large layers, T <= 32: persistent, one workgroup of 8 waves per CU walks the
+//                                  (sample, 128 x 256 tile) items of its XCD; v_mfma_f32_32x32x2_f32 fed by one
+//                                  ds_read_b32 + one ds_read_b128 per four MFMAs; rows leave as 16-byte non-temporal
+//                                  buffer stores; the next item's operands are prefetched into registers ahead of
+//                                  this item's stores.  Store-bound at T = 24 (5.4-5.8 TB/s of 6.0-6.2 achievable).
+//   linear_gs_split_kernel         large layers, T > 32 (any length): the fp32 contraction itself was the bound there
+//                                  (64 flop/cycle/SIMD on the fp32 matrix pipe), so every fp32 operand is split into
+//                                  three bf16 pieces when it is staged and the products run on the bf16 pipe
+//                                  (v_mfma_f32_32x32x16_bf16, 16x the rate), 6 of the 9 exact partial products per
+//                                  fp32 product (what is dropped is < 2^-26 of the product), fp32 accumulation.  Two workgroups of 4 waves per CU, 128 x 128 tiles,
+//                                  chunks of 32 steps, operands prefetched two chunks ahead.
+//
+// All three: every output element is a fixed-order sum (deterministic, independent of the grid); the epilogue emits
+// sum(GS^2) of the tile (+ the bias slice in column-tile 0) as ONE float per (sample, slot), so the norm pass of
+// DPOptimizer.clip_and_accumulate never re-reads the gradient; rows of the arena whose stride is a multiple of 32
+// floats are written as whole 128-byte lines.  Grids are XCD-aware (blocks id and id+8 share an XCD): a sample's
+// A/G slices are fetched into ONE XCD's L2 and re-read there by its other tiles.  Placement is used for speed only.
+// Slots: dpk_linear_slots() counts 128-column tiles for the large-layer plan (a 256-column tile owns two and writes 0
+// into the second), so that the three kernels agree on a layer's slot range.
 #include "dpk_common.h"
+#include <cstdlib>
+#include <cstring>
 
 namespace {
 
@@ -71,7 +79,7 @@ __global__ void __launch_bounds__(NW * 64) linear_gs_kernel(const float* __restr
                                                            float* __restrict__ normsq_part, int64_t part_stride,
                                                            int slot0, int B, int T, int in_f, int out_f,
                                                            int64_t gs_stride, int ld_w, int ld_g, float g_scale,
-                                                           int tiles_m, int tiles_n) {
+                                                           int tiles_m, int tiles_n, int slot_cols, int slot_mul) {
     constexpr int NTHR = NW * 64;
     constexpr int NCG = CS / (32 * NT);        // column groups per tile
     constexpr int UNITS = (RS / 32) * NCG;
@@ -208,7 +216,12 @@ __global__ void __launch_bounds__(NW * 64) linear_gs_kernel(const float* __restr
         sq += bias_acc * bias_acc;
     }
     const float tot = block_sum<NW>(sq, red);
-    if (threadIdx.x == 0) normsq_part[(int64_t)b * part_stride + slot0 + tile] = tot;
+    // a layer's slots are counted in 128-column tiles (dpk_linear_slots); a 256-column tile owns two of them
+    if (threadIdx.x == 0) {
+        float* pp = normsq_part + (int64_t)b * part_stride + slot0 + tm * slot_cols + tn * slot_mul;
+        pp[0] = tot;
+        if (slot_mul == 2 && tn * 2 + 1 < slot_cols) pp[1] = 0.f;
+    }
 }
 
 
@@ -273,7 +286,7 @@ __device__ __forceinline__ f32x4 mask4(f32x4 v, int left) {
 template <int NG, int NA>
 __global__ void __launch_bounds__(512) linear_gs_persist_wide_kernel(
     const K1Jobs jobs, float* __restrict__ normsq_part, int64_t part_stride, int B, int T, int in_f, int out_f,
-    int64_t gs_stride, int ld_w, int ld_g, float g_scale, int tiles_m, int tiles_n) {
+    int64_t gs_stride, int ld_w, int ld_g, float g_scale, int tiles_m, int tiles_n, int slot_cols) {
     constexpr int NW = 8, RS = 128, CS = 256, NTHR = NW * 64;
     constexpr int R4 = RS / 4, C4 = CS / 4;
     extern __shared__ __attribute__((aligned(16))) float smem[];  // [Tp][RS] G, [Tp][CS] A, 2 pad rows, red[2][NW]
@@ -433,9 +446,12 @@ __global__ void __launch_bounds__(512) linear_gs_persist_wide_kernel(
 #pragma unroll
             for (int i = 0; i < NW; ++i) tot += red[parity * NW + i];
             const auto rsP = make_rsrc(normsq_part + b * part_stride, (int64_t)part_stride * 4);
+            // slots are counted in 128-column tiles: this 256-column tile owns two (the second, if it exists, gets 0)
+            const bool second = tid == 1 && cur.tn * 2 + 1 < slot_cols;
             __builtin_amdgcn_raw_buffer_store_b32(
-                __builtin_bit_cast(unsigned, tot), rsP,
-                tid == 0 ? (unsigned)(jobs.slot0[cur.job] + cur.tm * tiles_n + cur.tn) * 4u : OOB, 0, 0);
+                __builtin_bit_cast(unsigned, tid == 0 ? tot : 0.f), rsP,
+                (tid == 0 || second) ? (unsigned)(jobs.slot0[cur.job] + cur.tm * slot_cols + cur.tn * 2 + tid) * 4u : OOB,
+                0, 0);
         }
         parity ^= 1;
         more = has_next;
@@ -445,6 +461,343 @@ __global__ void __launch_bounds__(512) linear_gs_persist_wide_kernel(
     // prefetch, which is what lets the compiler count them (vmcnt(N), N >= 17) instead of waiting for everything.
     do_item();
     while (more) do_item();
+}
+
+// ---- persistent, split-operand variant (round 2): fp32 products on the bf16 matrix pipe --------------------------
+// On gfx950 the fp32 MFMA (v_mfma_f32_32x32x2_f32: 64 flop per cycle per SIMD) is 16x slower than the bf16 one
+// (v_mfma_f32_32x32x16_bf16: 1024), and at T = 48 the fp32 contraction alone (12.3k cycles per 128 x 256 item) is longer
+// than the item's stores (9.2k cycles at 8 TB/s): K1 was MFMA-issue-bound, not HBM-bound.  Every fp32 number is the
+// sum of three bf16 numbers, x = x1 + x2 + x3 with x1 = bf16(x), x2 = bf16(x - x1), x3 = bf16(x - x1 - x2) (round to
+// nearest; both differences are exact, |x2| <= 2^-9 |x|, |x3| <= 2^-18 |x|, and what x3 leaves is below 2^-27 |x|),
+// a bf16 x bf16 product is exact in fp32, and the MFMA accumulates in fp32.  So
+//     g * a = sum_{p,q} g_p * a_q                                  (9 exact partial products)
+// and the kernel issues TERMS of the 9 bf16 MFMAs per fp32 one: 9 = every partial product; 8 drops only g_3*a_3
+// (<= 2^-36 |g a|); 6 drops p+q > 2 (<= 2^-26 |g a|: a quarter of the rounding error of the fp32 product itself,
+// 2^-24 |g a|).  Small terms are accumulated first.  The operands are split once, when they are staged into
+// LDS (4 VALU ops + 1.5 packs per element), as three k-contiguous bf16 images [piece][row or column][t], so one
+// ds_read_b128 is one MFMA operand (8 consecutive t of one row/column); rows are (2*kc+1)*16 bytes: an odd number of
+// 16-byte chunks makes both the b128 operand reads and the staging writes conflict-free.
+// Structure, item walk, prefetch, buffer addressing and stores are those of linear_gs_persist_wide_kernel; sequences
+// longer than 48 steps run as chunks of 48 with the accumulators kept across chunks (MULTI).  The bias slice is
+// summed in fp32 from the staged values (per 4-step group by the staging thread, groups in t order by the owner lane).
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+
+// {bf16(lo), bf16(hi)}, round to nearest even: one instruction packs a pair
+__device__ __forceinline__ unsigned pack_bf16_rn(float lo, float hi) {
+    unsigned r;
+    asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(r) : "v"(lo), "v"(hi));
+    return r;
+}
+// what the pair's two bf16 values leave of lo / hi: exact differences (the operands are within a factor of two)
+__device__ __forceinline__ float rest_lo(float lo, unsigned pk) { return lo - __builtin_bit_cast(float, pk << 16); }
+__device__ __forceinline__ float rest_hi(float hi, unsigned pk) { return hi - __builtin_bit_cast(float, pk & 0xffff0000u); }
+
+#ifndef DPK_K1_ABL
+#define DPK_K1_ABL 0  // lab ablations (results wrong): 1 = drop the stores, 2 = skip the MFMAs, 4 = skip the staging
+#endif
+#ifdef DPK_K1_STAMPS  // lab: per-phase cycle stamps of the split kernel (tools/lab/k1_stamps.py)
+__device__ unsigned long long dpk_stamps[64 * 8 * 9];
+#define STAMP(i)                                                     \
+    do {                                                             \
+        const unsigned long long now_ = __builtin_amdgcn_s_memtime(); \
+        st_acc[i] += now_ - st_last;                                 \
+        st_last = now_;                                              \
+    } while (0)
+#else
+#define STAMP(i)
+#endif
+constexpr int SPLIT_TC = 32;    // time steps per LDS chunk (2 MFMA k-steps of 16)
+constexpr int SPLIT_NQ = 8;     // 4-step groups per chunk
+constexpr int SPLIT_CS = 128;   // tile: 128 (out) x 128 (in)
+
+// Two workgroups of 4 waves per CU (one wave of each per SIMD, <= 256 registers, 66 KB of LDS each): while one
+// workgroup splits and stages a chunk (VALU + LDS writes) the other contracts or stores (matrix pipe, vector memory).
+// A wave owns one 32 x 128 unit of the 128 x 128 tile and keeps TWO chunks of prefetched operands in registers: a
+// chunk's loads are issued two chunks before they are staged, so the chain "loads land -> split and stage -> issue the
+// next loads" (load latency behind a CU's own stores is 4-6 us, a chunk's MFMAs take 1) does not pace the kernel.
+template <int TERMS, bool MULTI>
+__global__ void __launch_bounds__(256, 2) linear_gs_split_kernel(
+    const K1Jobs jobs, float* __restrict__ normsq_part, int64_t part_stride, int B, int T, int in_f, int out_f,
+    int64_t gs_stride, int ld_w, int ld_g, float g_scale, int tiles_m, int tiles_n, int rowch) {
+    constexpr int NW = 4, RS = 128, CS = SPLIT_CS, NTHR = NW * 64, NR = 2;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_b[];
+    const int ROWB = rowch * 16;                 // bytes per row/column of one piece image
+    const int PS = RS * ROWB;                    // piece stride (RS == CS)
+    unsigned char* sG = smem_b;                  // [3][RS][ROWB]
+    unsigned char* sA = smem_b + 3 * PS;         // [3][CS][ROWB]
+    float* sBias = reinterpret_cast<float*>(sA + 3 * PS);  // [SPLIT_NQ][RS]
+    float* red = sBias + SPLIT_NQ * RS;                    // [2][NW]
+
+    // ---- XCD-aware walk over (job, sample slot, tile row, tile column, chunk) ----------------------------------------
+    const int ntile = tiles_m * tiles_n;
+    const int xcd = blockIdx.x & 7;
+    const int nbx = gridDim.x >> 3;
+    const int nsx = (B - xcd + 7) / 8;
+    const int nch = MULTI ? (T + SPLIT_TC - 1) / SPLIT_TC : 1;
+    struct Cur {
+        int job, s, tm, tn, c;
+    };
+    const int d_s = nbx / ntile, d_tm = (nbx % ntile) / tiles_n, d_tn = nbx % tiles_n;
+    auto next = [&](Cur x) {
+        if (MULTI && x.c + 1 < nch) { ++x.c; return x; }
+        x.c = 0;
+        x.tn += d_tn;
+        if (x.tn >= tiles_n) { x.tn -= tiles_n; ++x.tm; }
+        x.tm += d_tm;
+        if (x.tm >= tiles_m) { x.tm -= tiles_m; ++x.s; }
+        x.s += d_s;
+        while (x.s >= nsx && x.job < jobs.n) { x.s -= nsx; ++x.job; }  // job == jobs.n: past the last item
+        return x;
+    };
+    Cur cur;
+    {
+        const int w = blockIdx.x >> 3;
+        cur.job = 0;
+        cur.c = 0;
+        cur.s = w / ntile;
+        cur.tm = (w % ntile) / tiles_n;
+        cur.tn = w % tiles_n;
+        while (cur.s >= nsx && cur.job < jobs.n) { cur.s -= nsx; ++cur.job; }
+    }
+    if (nsx <= 0 || cur.job >= jobs.n) return;  // uniform
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int l31 = lane & 31;
+    const int lh = lane >> 5;
+    const int mr = wave;  // this wave's 32 x 128 unit: MFMA row block mr = features m0 + 4*slot + mr
+
+    // chunk c: steps [32 c, ...), kc k-steps of 16, nq staged 4-step groups (MULTI stages whole k-steps: the groups past
+    // the sequence end are loaded out of range = zeros; single-chunk mode zeroes them once, below)
+    auto chunk_kc = [&](int c) { const int len = min(SPLIT_TC, T - c * SPLIT_TC); return (len + 15) >> 4; };
+    auto chunk_nq = [&](int c) { return MULTI ? 4 * chunk_kc(c) : (T + 3) >> 2; };
+
+    // staging tasks of a chunk: task = (4-step group tq, 4 adjacent columns cgp*4..+3); [0, Gpad) are G's, then A's;
+    // a wave's 64 tasks are all of one kind (Gpad is a multiple of 64): the descriptor is chosen with scalar code.
+    // A cursor past the last item fetches nothing (empty descriptor), so there is no branch around the loads.
+    f32x4 rq[2][NR][4];
+    auto prefetch = [&](f32x4 (&r)[NR][4], const Cur& x) {
+        const bool valid = x.job < jobs.n;
+        const int job = valid ? x.job : 0;
+        const int64_t b = x.s * 8 + xcd;
+        const int nq = chunk_nq(x.c), t0 = x.c * SPLIT_TC;
+        const int Gpad = (32 * nq + 63) & ~63;
+#pragma unroll
+        for (int k = 0; k < NR; ++k) {
+            const int wbase = wave * 64 + k * NTHR;
+            const bool isG = wbase < Gpad;
+            const float* base = isG ? jobs.G[job] + b * T * ld_g : jobs.A[job] + b * T * in_f;
+            // rows at or past T lie beyond the descriptor: no per-row test
+            const int64_t bytes = !valid ? 0 : isG ? ((int64_t)(T - 1) * ld_g + out_f) * 4 : (int64_t)T * in_f * 4;
+            const auto rs = make_rsrc(base, bytes);
+            const int idx = wbase + lane - (isG ? 0 : Gpad);
+            const int tq = idx >> 5;
+            const int col = (isG ? x.tm * RS : x.tn * CS) + (idx & 31) * 4;
+            const int ld = isG ? ld_g : in_f;
+            const int dim = isG ? out_f : in_f;
+            unsigned off = (tq < nq && col < dim) ? (unsigned)((t0 + 4 * tq) * ld + col) * 4u : OOB;
+            const unsigned rowb = (unsigned)ld * 4u;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                r[k][i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, off, 0, 0));
+                off += rowb;  // an out-of-range offset stays out of range
+            }
+        }
+    };
+    auto stage = [&](const f32x4 (&r)[NR][4], const Cur& x) {  // prefetched registers -> three bf16 images in LDS
+        const int nq = chunk_nq(x.c);
+        const int Gpad = (32 * nq + 63) & ~63;
+#pragma unroll
+        for (int k = 0; k < NR; ++k) {
+            const int wbase = wave * 64 + k * NTHR;
+            const bool isG = wbase < Gpad;
+            const int idx = wbase + lane - (isG ? 0 : Gpad);
+            const int tq = idx >> 5;
+            const int cgp = idx & 31;
+            const int left = isG ? out_f - (x.tm * RS + cgp * 4) : in_f - (x.tn * CS + cgp * 4);
+            if (tq < nq) {
+                f32x4 v[4];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) v[i] = mask4(r[k][i], left);
+                if (isG) {
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) v[i] *= g_scale;
+                    *reinterpret_cast<f32x4*>(sBias + tq * RS + cgp * 4) = (v[0] + v[1]) + (v[2] + v[3]);
+                }
+                // column 4*cgp+e of the tile -> position e*32 + cgp (slot cgp of MFMA block e), for G and for A
+                unsigned char* dst = (isG ? sG : sA) + cgp * ROWB + tq * 8;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    float x0 = v[0][e], x1 = v[1][e], x2 = v[2][e], x3 = v[3][e];
+                    unsigned char* d = dst + e * 32 * ROWB;
+#pragma unroll
+                    for (int p = 0; p < 3; ++p) {
+                        const u32x2 w = {pack_bf16_rn(x0, x1), pack_bf16_rn(x2, x3)};
+                        *reinterpret_cast<u32x2*>(d + p * PS) = w;
+                        if (p < 2) {
+                            x0 = rest_lo(x0, w[0]);
+                            x1 = rest_hi(x1, w[0]);
+                            x2 = rest_lo(x2, w[1]);
+                            x3 = rest_hi(x3, w[1]);
+                        }
+                    }
+                }
+            }
+        }
+    };
+
+    if constexpr (!MULTI) {  // k positions between the sequence end and the end of the last k-step: zero, once
+        const int nq = (T + 3) >> 2, nqz = 4 * chunk_kc(0) - nq;
+        if (nqz > 0) {
+            const int tot = 3 * (RS + CS) * nqz;
+            for (int idx = tid; idx < tot; idx += NTHR) {
+                const int pos = idx / nqz, q = nq + (idx - pos * nqz);  // pos walks [3][RS] then [3][CS]: contiguous rows
+                const u32x2 z = {0u, 0u};
+                *reinterpret_cast<u32x2*>(smem_b + pos * ROWB + q * 8) = z;
+            }
+        }
+    }
+
+#ifdef DPK_K1_STAMPS
+    unsigned long long st_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, st_last = 0, st_items = 0;
+#endif
+    Cur n1 = next(cur);
+    Cur n2 = next(n1);
+    prefetch(rq[0], cur);
+    prefetch(rq[1], n1);
+    int parity = 0;
+    f32x16 acc[4];
+    float bsum = 0.f;
+    // one chunk: stage its operands (fetched two chunks ago), fetch the chunk two ahead into the freed registers,
+    // contract; on an item's last chunk store the unit and publish the tile's squared norm
+    auto step = [&](f32x4 (&r)[NR][4]) {
+        const int m0 = cur.tm * RS, n0 = cur.tn * CS;
+        const int64_t b = cur.s * 8 + xcd;
+        if (cur.c == 0) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+                for (int q = 0; q < 16; ++q) acc[j][q] = 0.f;
+            bsum = 0.f;
+        }
+#ifdef DPK_K1_STAMPS
+        st_last = __builtin_amdgcn_s_memtime();
+        ++st_items;
+#if DPK_K1_STAMPS == 2
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        STAMP(7);
+#endif
+#endif
+        if (!(DPK_K1_ABL & 4)) stage(r, cur);
+        STAMP(0);
+        lds_only_barrier();
+        STAMP(1);
+        // the first k-step's operands are requested before the prefetch is issued: their LDS latency passes under the
+        // prefetch's address arithmetic, and each later k-step's under the tail of the previous one's MFMAs
+        const unsigned char* pg = sG + (mr * 32 + l31) * ROWB + lh * 16;
+        const unsigned char* pa = sA + l31 * ROWB + lh * 16;
+        bf16x8 g[3], a[3][4];
+        auto load_ops = [&]() {
+#pragma unroll
+            for (int p = 0; p < 3; ++p) g[p] = *reinterpret_cast<const bf16x8*>(pg + p * PS);
+#pragma unroll
+            for (int q = 0; q < 3; ++q)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) a[q][j] = *reinterpret_cast<const bf16x8*>(pa + q * PS + j * 32 * ROWB);
+            pg += 32;
+            pa += 32;
+        };
+        load_ops();
+        prefetch(r, n2);  // ahead of this item's stores in the vector-memory pipe
+        STAMP(2);
+        if (!(DPK_K1_ABL & 2)) {
+            const int kc = chunk_kc(cur.c);
+            for (int ks = 0; ks < kc; ++ks) {
+#pragma unroll
+                for (int sum = 4; sum >= 0; --sum)  // smallest partial products first
+#pragma unroll
+                    for (int p = 2; p >= 0; --p) {
+                        const int q = sum - p;
+                        if (q < 0 || q > 2) continue;
+                        if (TERMS == 8 && sum == 4) continue;
+                        if (TERMS == 6 && sum > 2) continue;
+#pragma unroll
+                        for (int j = 0; j < 4; ++j)
+                            acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(g[p], a[q][j], acc[j], 0, 0, 0);
+                    }
+                if (ks + 1 < kc) load_ops();
+            }
+            if (lh == 0) {  // bias: feature 4*l31 + mr, the chunk's 4-step groups in t order
+                const int nq = chunk_nq(cur.c);
+                for (int q = 0; q < nq; ++q) bsum += sBias[q * RS + 4 * l31 + mr];
+            }
+        }
+        STAMP(3);
+        if (!MULTI || cur.c == nch - 1) {
+            // stores: accumulator row slot m = (q&3) + 8*(q>>2) + 4*lh of MFMA block mr is feature m0 + 4*m + mr; rows
+            // >= out_f fall outside the descriptor, columns >= ld_w get the out-of-range offset
+            float sq = 0.f;
+            const auto rsW = make_rsrc(jobs.W[cur.job] + b * gs_stride, (int64_t)out_f * ld_w * 4);
+            const int col = n0 + 4 * l31;
+            const unsigned row_bytes = (unsigned)ld_w * 4u;
+            unsigned soff = col < ld_w ? (unsigned)((m0 + mr + 16 * lh) * ld_w + col) * 4u : OOB;
+            if (DPK_K1_ABL & 1) soff = OOB;
+#pragma unroll
+            for (int q = 0; q < 16; ++q) {
+                const f32x4 v = {acc[0][q], acc[1][q], acc[2][q], acc[3][q]};
+                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), rsW, soff, 0, DPK_K1_STORE_AUX);
+                soff += ((q & 3) == 3 ? 20u : 4u) * row_bytes;  // slots 0 1 2 3 8 9 10 11 ... -> rows 4*slot
+                sq += v[0] * v[0];
+                sq += v[1] * v[1];
+                sq += v[2] * v[2];
+                sq += v[3] * v[3];
+            }
+            {
+                const float* GSb = jobs.Bi[cur.job];
+                const bool has_bias = GSb != nullptr && cur.tn == 0;
+                const auto rsB = make_rsrc(GSb + b * gs_stride, has_bias ? (int64_t)out_f * 4 : 0);
+                const int f = m0 + 4 * l31 + mr;
+                __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, bsum), rsB,
+                                                      lh == 0 ? (unsigned)f * 4u : OOB, 0, 0);
+                if (has_bias && lh == 0 && f < out_f) sq += bsum * bsum;
+            }
+            STAMP(4);
+            sq = wave_sum(sq);
+            if (lane == 0) red[parity * NW + wave] = sq;
+            lds_only_barrier();  // every wave is done with this item's images; red[parity] is complete
+            {
+                float tot = 0.f;
+#pragma unroll
+                for (int i = 0; i < NW; ++i) tot += red[parity * NW + i];
+                const auto rsP = make_rsrc(normsq_part + b * part_stride, (int64_t)part_stride * 4);
+                __builtin_amdgcn_raw_buffer_store_b32(
+                    __builtin_bit_cast(unsigned, tot), rsP,
+                    tid == 0 ? (unsigned)(jobs.slot0[cur.job] + cur.tm * tiles_n + cur.tn) * 4u : OOB, 0, 0);
+            }
+            parity ^= 1;
+        } else {
+            lds_only_barrier();  // all waves done with this chunk's images
+        }
+        STAMP(5);
+        cur = n1;
+        n1 = n2;
+        n2 = next(n2);
+        STAMP(6);
+    };
+    for (;;) {
+        step(rq[0]);
+        if (cur.job >= jobs.n) break;
+        step(rq[1]);
+        if (cur.job >= jobs.n) break;
+    }
+#ifdef DPK_K1_STAMPS
+    if (blockIdx.x < 64 && lane == 0) {
+        for (int i = 0; i < 8; ++i) dpk_stamps[(blockIdx.x * 8 + wave) * 9 + i] = st_acc[i];
+        dpk_stamps[(blockIdx.x * 8 + wave) * 9 + 8] = st_items;
+    }
+#endif
 }
 
 #ifdef DPK_K1_PIPE  // lab builds only: the software-pipelined variant (measured, not adopted: DESIGN.md 8.5)
@@ -464,6 +817,20 @@ inline int dpk_cu_count() {
 }
 
 constexpr int PERSIST_MAX_T = 48;
+
+// Which MFMA the large-layer path uses.  DPK_K1_MFMA = "f32" (v_mfma_f32_32x32x2_f32, the wide-unit kernel; T <= 48),
+// "split6" | "split8" | "split9" (bf16 pipe, that many exact partial products per fp32 product, any T).  Unset: the
+// faster of the two as measured: f32 up to 32 steps, where the kernel is store-bound either way and
+// the split's staging work only costs; split6 beyond, where the fp32 contraction is what the stores wait for.
+// Read at every launch (a getenv, ~0.1 us) so one process can time both.  Returns 0 for f32, else the term count.
+inline int k1_mode(int T) {
+    const char* e = getenv("DPK_K1_MFMA");
+    if (e && !strcmp(e, "split6")) return 6;
+    if (e && !strcmp(e, "split8")) return 8;
+    if (e && !strcmp(e, "split9")) return 9;
+    if (e && !strcmp(e, "f32")) return T <= PERSIST_MAX_T ? 0 : 6;
+    return T <= 32 ? 0 : 6;
+}
 
 struct Plan {
     int id;      // which instantiation
@@ -488,8 +855,8 @@ extern "C" int dpk_linear_slots(int in_features, int out_features) {
     if (in_features <= 0 || out_features <= 0) return DPK_EINVAL;
     const Plan p = pick_plan(in_features, out_features);
     const int tiles_m = (out_features + p.rs - 1) / p.rs;
-    const int tiles_n = (in_features + p.cs - 1) / p.cs;
-    return tiles_m * tiles_n;
+    const int slot_w = p.id == 0 ? SPLIT_CS : p.cs;  // the large-layer plan counts its slots in 128-column tiles
+    return tiles_m * ((in_features + slot_w - 1) / slot_w);
 }
 
 namespace {
@@ -504,10 +871,12 @@ int k1_launch(const float* const* A, const float* const* G, float* const* GSw, f
     const int tiles_m = (out_f + p.rs - 1) / p.rs;
     const int tiles_n = (in_f + p.cs - 1) / p.cs;
     const int64_t ntile = (int64_t)tiles_m * tiles_n;
+    const int slot_cols = p.id == 0 ? (in_f + SPLIT_CS - 1) / SPLIT_CS : tiles_n;  // as dpk_linear_slots counts them
+    const int slot_mul = p.id == 0 ? 2 : 1;
     int nt_store = (ld_w % 32 == 0) && (gs_stride % 32 == 0);
     for (int j = 0; j < n_jobs; ++j) {
         if (!A[j] || !G[j] || !GSw[j] || slot0[j] < 0) return DPK_EINVAL;
-        if (slot0[j] + ntile > part_stride) return DPK_ESLOTS;
+        if (slot0[j] + (int64_t)tiles_m * slot_cols > part_stride) return DPK_ESLOTS;
         // whole 128-byte lines per store segment: row stride and every row start multiples of 32 floats
         nt_store = nt_store && ((((uintptr_t)GSw[j]) & 127u) == 0);
     }
@@ -518,7 +887,7 @@ int k1_launch(const float* const* A, const float* const* G, float* const* GSw, f
     // Large layers (the 128 x 256 plan) at T <= 48: the persistent wide-unit kernel.  Its 16-byte row stores need a row
     // stride that is a multiple of 4 floats (the arena's is a multiple of 32: whole 128-byte lines); anything else
     // takes the launch-per-tile kernel below.
-    if (p.id == 0 && T <= PERSIST_MAX_T && ld_w % 4 == 0) {
+    if (p.id == 0 && ld_w % 4 == 0 && (int64_t)out_f * ld_w < (1LL << 29) && (int64_t)T * (ld_g > in_f ? ld_g : in_f) < (1LL << 29)) {
         K1Jobs jobs;
         for (int j = 0; j < DPK_K1_MAX_JOBS; ++j) {
             const int q = j < n_jobs ? j : 0;
@@ -526,8 +895,8 @@ int k1_launch(const float* const* A, const float* const* G, float* const* GSw, f
             jobs.slot0[j] = slot0[q];
         }
         jobs.n = n_jobs;
-        const int Tp = (T + 1) & ~1;
-#define DPK_K1_PERSIST_GO(KFN, LDS_BYTES)                                                                        \
+        const int mode = k1_mode(T);
+#define DPK_K1_PERSIST_GO(NTHREADS, KFN, LDS_BYTES, ...)                                                         \
     do {                                                                                                         \
         auto kfn = KFN;                                                                                          \
         if ((LDS_BYTES) > 64 * 1024) {                                                                           \
@@ -535,27 +904,45 @@ int k1_launch(const float* const* A, const float* const* G, float* const* GSw, f
                                                 (int)(LDS_BYTES));                                               \
             if (e_ != hipSuccess) return (int)e_;                                                                \
         }                                                                                                        \
-        hipLaunchKernelGGL(kfn, pgrid, dim3(512), (LDS_BYTES), s, jobs, normsq_part, part_stride, B, T, in_f,    \
-                           out_f, gs_stride, ld_w, ld_g, g_scale, tiles_m, tiles_n);                             \
+        hipLaunchKernelGGL(kfn, pgrid, dim3(NTHREADS), (LDS_BYTES), s, jobs, normsq_part, part_stride, B, T, in_f, \
+                           out_f, gs_stride, ld_w, ld_g, g_scale, tiles_m, __VA_ARGS__);                         \
     } while (0)
-        // one workgroup of 8 waves per CU (128 / 150 registers at T <= 32 / 48; two per CU measured slower)
-        int64_t want = dpk_cu_count();
-        if (want > nblk * n_jobs) want = nblk * n_jobs;
-        const dim3 pgrid((unsigned)((want + 7) / 8 * 8));
-#ifdef DPK_K1_PIPE  // lab builds only
-        if (nt_store && T > 32) {
-            const size_t lds2 = ((size_t)2 * Tp * (128 + 256) + 2 * 256 + 2 * 8) * sizeof(float);
-            DPK_K1_PERSIST_GO(linear_gs_pipe_kernel, lds2);
+        if (mode != 0) {
+            // split-operand kernel: exact fp32 products on the bf16 matrix pipe, any sequence length; 128 x 128 tiles,
+            // two workgroups of 4 waves per CU
+            const int64_t items = ((int64_t)(B + 7) / 8) * 8 * tiles_m * slot_cols * n_jobs;
+            int64_t want = 2 * (int64_t)dpk_cu_count();
+            if (want > items) want = items;
+            const dim3 pgrid((unsigned)((want + 7) / 8 * 8));
+            const int kcmax = T >= 17 ? 2 : 1;
+            const int rowch = 2 * kcmax + 1;
+            const size_t lds = (size_t)3 * (128 + SPLIT_CS) * rowch * 16 + (SPLIT_NQ * 128 + 2 * 4) * sizeof(float);
+            const bool multi = T > SPLIT_TC;
+#define DPK_K1_SPLIT_TERMS(MULTIV)                                                                               \
+    do {                                                                                                         \
+        if (mode == 6) DPK_K1_PERSIST_GO(256, (linear_gs_split_kernel<6, MULTIV>), lds, slot_cols, rowch);       \
+        else if (mode == 9) DPK_K1_PERSIST_GO(256, (linear_gs_split_kernel<9, MULTIV>), lds, slot_cols, rowch);  \
+        else DPK_K1_PERSIST_GO(256, (linear_gs_split_kernel<8, MULTIV>), lds, slot_cols, rowch);                 \
+    } while (0)
+            if (multi) DPK_K1_SPLIT_TERMS(true);
+            else DPK_K1_SPLIT_TERMS(false);
+#undef DPK_K1_SPLIT_TERMS
             return dpk_launch_status();
         }
-#endif
-        const size_t lds = ((size_t)Tp * (128 + 256) + 2 * 256 + 2 * 8) * sizeof(float);  // + 2 readable pad rows
-        if (T <= 32)
-            DPK_K1_PERSIST_GO((linear_gs_persist_wide_kernel<2, 4>), lds);
-        else
-            DPK_K1_PERSIST_GO((linear_gs_persist_wide_kernel<3, 6>), lds);
+        if (T <= PERSIST_MAX_T) {  // DPK_K1_MFMA=f32: the fp32-MFMA wide-unit kernel (reference point for A/B timing)
+            // one workgroup of 8 waves per CU
+            int64_t want = dpk_cu_count();
+            if (want > nblk * n_jobs) want = nblk * n_jobs;
+            const dim3 pgrid((unsigned)((want + 7) / 8 * 8));
+            const int Tp = (T + 1) & ~1;
+            const size_t lds = ((size_t)Tp * (128 + 256) + 2 * 256 + 2 * 8) * sizeof(float);  // + 2 readable pad rows
+            if (T <= 32)
+                DPK_K1_PERSIST_GO(512, (linear_gs_persist_wide_kernel<2, 4>), lds, tiles_n, slot_cols);
+            else
+                DPK_K1_PERSIST_GO(512, (linear_gs_persist_wide_kernel<3, 6>), lds, tiles_n, slot_cols);
+            return dpk_launch_status();
+        }
 #undef DPK_K1_PERSIST_GO
-        return dpk_launch_status();
     }
     dim3 grid((unsigned)nblk);
     const bool stream_mode = T <= STREAM_MAX_T;
@@ -569,7 +956,7 @@ int k1_launch(const float* const* A, const float* const* G, float* const* GSw, f
     for (int j = 0; j < n_jobs; ++j)                                                                             \
         hipLaunchKernelGGL((linear_gs_kernel<NW, RS, CS, NT, ST, NTS>), grid, dim3(NW * 64), lds, s, A[j], G[j], \
                            GSw[j], GSb ? GSb[j] : nullptr, normsq_part, part_stride, slot0[j], B, T, in_f,      \
-                           out_f, gs_stride, ld_w, ld_g, g_scale, tiles_m, tiles_n)
+                           out_f, gs_stride, ld_w, ld_g, g_scale, tiles_m, tiles_n, slot_cols, slot_mul)
 #define DPK_K1_LAUNCH(NW, RS, CS, NT)                                                                          \
     do {                                                                                                       \
         const size_t lds = ((size_t)lds_rows * (RS + CS) + NW) * sizeof(float);                                \
@@ -591,6 +978,12 @@ int k1_launch(const float* const* A, const float* const* G, float* const* GSw, f
 }
 
 }  // namespace
+
+#ifdef DPK_K1_STAMPS
+extern "C" int dpk_lab_read_stamps(void* host, int n) {
+    return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(dpk_stamps), sizeof(unsigned long long) * n);
+}
+#endif
 
 extern "C" int dpk_linear_grad_sample(const float* A, const float* G, float* GSw, float* GSb, float* normsq_part,
                                       int64_t part_stride, int slot0, int B, int T, int in_f, int out_f,

@@ -62,6 +62,11 @@ int dpk_normsq_slots(int64_t P);
  * that every store is a whole 128-byte line); columns [in, ld_w) are written as zeros.
  * g_scale = batch size for loss_reduction="mean" (Opacus multiplies backprops by n first; so do we).
  * Writes dpk_linear_slots(in,out) normsq partials per sample, covering weight and bias.
+ * Arithmetic: fp32 in, fp32 out, fp32 accumulation in t order.  Small layers and sequences of up to 32 steps use
+ * the fp32 matrix instruction; large layers (in > 128, out > 32) at T > 32 split each fp32 operand into three bf16
+ * pieces (to 2^-27 of its value) and form 6 of the 9 exact partial products per fp32 product on the bf16 matrix pipe
+ * (what is dropped is below 2^-26 of the product: a quarter of the fp32 product's own rounding).  The environment variable DPK_K1_MFMA = f32 | split6 | split8 | split9, read at every
+ * call, overrides the choice (lab and A/B timing; k1_linear_gs.hip::k1_mode).
  */
 int dpk_linear_grad_sample(const float* A, const float* G, float* GSw, float* GSb,
                            float* normsq_part, int64_t part_stride, int slot0,

@@ -396,6 +396,9 @@ ARENA_SHAPES = [
     (70, 24, 512, 512, 1), (33, 24, 256, 128, 6), (17, 24, 400, 200, 6), (40, 24, 208, 208, 1),   # cfg2 / cfg1 layers
     (3, 1, 130, 33, 1), (4, 31, 300, 260, 2), (2, 47, 129, 129, 3), (300, 12, 160, 40, 1), (1, 48, 512, 97, 1),
     (13, 32, 384, 70, 1), (5, 33, 640, 64, 1),
+    # beyond 32 steps the large layers run as 32-step chunks on the split-operand kernel (cfg5: T = 256)
+    (3, 256, 512, 512, 1), (4, 70, 300, 260, 2), (2, 100, 129, 129, 3), (5, 49, 250, 250, 1), (2, 33, 640, 140, 1),
+    (3, 64, 256, 128, 1), (2, 40, 1024, 40, 1), (9, 36, 130, 33, 1),
 ]
 
 
@@ -470,3 +473,38 @@ def test_linear_grad_sample_arena_layout_many_items_is_deterministic(nat):
     w = outs[0][0][:, :win].reshape(B, out_f, ld)[:, :, :in_f].double()
     err = (w - ref).abs().amax((1, 2)) / ref.abs().amax((1, 2))
     assert float(err.max()) < TOL
+
+
+@pytest.mark.parametrize("B,T,in_f,out_f", [(6, 48, 300, 260), (4, 24, 512, 512), (3, 256, 512, 384), (5, 70, 250, 1000)])
+def test_linear_grad_sample_arithmetic_modes_are_fp32_accurate(nat, monkeypatch, B, T, in_f, out_f):
+    """The large-layer kernels compute fp32 products either on the fp32 matrix pipe (DPK_K1_MFMA=f32) or as 6 / 8 / 9
+    of the 9 exact partial products of a three-way bf16 split (split6 / split8 / split9; k1_linear_gs.hip).  Against a
+    float64 contraction of the same fp32 inputs every mode must be an fp32-grade result: error below 1e-6 of the
+    sample's largest entry (the path's tolerance is 1e-5), and dropping partial products (split6) must cost no more
+    than the accumulation rounding that all modes share."""
+    g = torch.Generator().manual_seed(T + in_f)
+    A = (torch.randn(B, T, in_f, generator=g) * torch.logspace(-3, 3, in_f)).cuda()   # 6 decades across columns
+    G = (torch.randn(B, T, out_f, generator=g) * 0.01).cuda()
+    ld = (in_f + 31) // 32 * 32
+    ref = torch.einsum("bto,bti->boi", G.double() * B, A.double())
+    ref_b = (G.double() * B).sum(1)
+    errs = {}
+    for mode in ("f32", "split6", "split8", "split9", None):
+        if mode is None:
+            monkeypatch.delenv("DPK_K1_MFMA", raising=False)
+        else:
+            monkeypatch.setenv("DPK_K1_MFMA", mode)
+        base = torch.zeros(B, ld * out_f + 64 * ((out_f + 63) // 64), device="cuda")
+        part = torch.zeros(B, nat.linear_slots(in_f, out_f), device="cuda")
+        nat.linear_grad_sample(A, G, nat.FlatView(base, 0, ld * out_f), nat.FlatView(base, ld * out_f, out_f), part, 0,
+                               float(B), ld_w=ld)
+        w = base[:, :ld * out_f].reshape(B, out_f, ld)[:, :, :in_f].double()
+        # column by column: every column judged against its own scale (the columns span six decades)
+        err = ((w - ref).abs().amax(1) / ref.abs().amax(1)).max()
+        errs[mode] = float(err)
+        assert float(err) < 1e-6, (mode, float(err))
+        assert float(((base[:, ld * out_f:ld * out_f + out_f].double() - ref_b).abs() / ref_b.abs().amax()).max()) < 1e-6
+        sq = (ref ** 2).sum((1, 2)) + (ref_b ** 2).sum(1)
+        assert float((part.double().sum(1) / sq - 1).abs().max()) < 1e-6, mode
+    assert errs["split6"] <= 2.0 * errs["split9"] + 2e-8, errs
+    assert errs["split8"] <= 1.25 * errs["split9"] + 1e-8, errs

@@ -19,6 +19,7 @@ SHAPES = {
     "cfg2": [(24, 512, 512, 1), (24, 256, 128, 6), (24, 512, 128, 1)],
     "cfg1": [(24, 400, 200, 6), (24, 208, 208, 1)],
     "lab": [(48, 512, 512, 1), (24, 512, 512, 1)],
+    "cfg5": [(256, 512, 512, 1), (256, 1024, 512, 1)],
 }
 
 
@@ -42,7 +43,14 @@ def main():
     ap.add_argument("--rounds", type=int, default=4)
     ap.add_argument("--bias", type=int, default=1)
     args = ap.parse_args()
-    libs = [(os.path.basename(p), load(p)) for p in args.libs]
+    # "path.so@mode" runs that library with DPK_K1_MFMA=mode (f32 | split6 | split8 | split9)
+    modes = {}
+    libs = []
+    for p in args.libs:
+        path, _, mode = p.partition("@")
+        name = os.path.basename(path) + ("@" + mode if mode else "")
+        modes[name] = mode
+        libs.append((name, load(path)))
     names = sum((SHAPES[k] for k in (SHAPES if args.shapes == "all" else args.shapes.split(","))), [])
     stream = c_void_p(torch.cuda.current_stream().cuda_stream)
     for T, in_f, out_f, nj in names:
@@ -64,7 +72,9 @@ def main():
         pb = arr([arena.data_ptr() + 4 * (j * (win + (out_f + 63) // 64 * 64) + win) for j in range(nj)])
         sl = (c_int * nj)(*[j * slots for j in range(nj)])
 
-        def run(lib):
+        def run(lib, name=None):
+            if name is not None and modes.get(name):
+                os.environ["DPK_K1_MFMA"] = modes[name]
             rc = lib.dpk_linear_grad_sample_group(pa, pg, pw, pb if args.bias else None, sl, nj, c_void_p(part.data_ptr()),
                                                   part.stride(0), B, T, in_f, out_f, row, ld, out_f, float(B), stream)
             if rc:
@@ -73,13 +83,13 @@ def main():
         times = {n: [] for n, _ in libs}
         for n, lib in libs:  # correctness first
             arena.zero_(); part.zero_()
-            run(lib)
+            run(lib, n)
             torch.cuda.synchronize()
             outs.append((n, arena[:64].clone(), arena[-8:].clone(), part.clone()))
         for _ in range(args.rounds):
             for n, lib in libs:
                 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-                run(lib)
+                run(lib, n)
                 e0.record()
                 for _ in range(args.iters):
                     run(lib)

@@ -25,10 +25,12 @@ host = (ctypes.c_ulonglong * n)()
 lib.dpk_lab_read_stamps.argtypes = [c_void_p, c_int]
 assert lib.dpk_lab_read_stamps(host, n) == 0
 a = np.array(host[:], dtype=np.float64).reshape(64, 8, 9)
+NWV = int(os.environ.get('NWAVES', '8'))
+a = a[:, :NWV]
 names = sys.argv[6].split(",") if len(sys.argv) > 6 else [f"p{i}" for i in range(8)]
 items = a[..., 8]
 tot = a[..., :8].sum(-1)
 print(f"items per WG: {items.mean():.1f}; cycles per item per wave: {(tot / items).mean():.0f}")
-for w in range(8):
+for w in range(NWV):
     print(f"wave {w}: " + "  ".join(f"{names[i]}={a[:, w, i].sum() / items[:, w].sum():7.0f}" for i in range(8)))
 print("all   : " + "  ".join(f"{names[i]}={a[..., i].sum() / items.sum():7.0f}" for i in range(8)))
