@@ -511,26 +511,34 @@ constexpr int SPLIT_TC = 32;    // time steps per LDS chunk (2 MFMA k-steps of 1
 constexpr int SPLIT_NQ = 8;     // 4-step groups per chunk
 constexpr int SPLIT_CS = 128;   // tile: 128 (out) x 128 (in)
 
-// Two workgroups of 4 waves per CU (one wave of each per SIMD, <= 256 registers, 66 KB of LDS each): while one
+// Two workgroups of 4 waves per CU (one wave of each per SIMD, <= 256 registers, <= 78 KB of LDS each): while one
 // workgroup splits and stages a chunk (VALU + LDS writes) the other contracts or stores (matrix pipe, vector memory).
-// A wave owns one 32 x 128 unit of the 128 x 128 tile and keeps TWO chunks of prefetched operands in registers: a
-// chunk's loads are issued two chunks before they are staged, so the chain "loads land -> split and stage -> issue the
+// A wave owns one 32 x 128 unit of the 128 x 128 tile and keeps TWO steps of prefetched operands in registers: a
+// step's loads are issued two steps before they are staged, so the chain "loads land -> split and stage -> issue the
 // next loads" (load latency behind a CU's own stores is 4-6 us, a chunk's MFMAs take 1) does not pace the kernel.
-template <int TERMS, bool MULTI>
+// A workgroup walks GROUPS (job, sample, column tile) of its XCD and, inside a group, the row tiles: the tiles of one
+// group share their A slice.  MODE 2 (32 < T <= 48: the denoiser's T = 48) keeps that slice's images resident in LDS
+// for the whole group — A is fetched, split and staged once per group instead of once per tile (44 % of the staging
+// work and of the operand fetches at 8 row tiles per group) — and streams G in chunks of 32 steps; MODE 1 (T > 48)
+// and MODE 0 (T <= 32) stage both operands per 32-step chunk (the group order still puts a slice's re-reads next to
+// each other in time: L2 hits instead of fabric fetches).
+template <int TERMS, int MODE>
 __global__ void __launch_bounds__(256, 2) linear_gs_split_kernel(
     const K1Jobs jobs, float* __restrict__ normsq_part, int64_t part_stride, int B, int T, int in_f, int out_f,
-    int64_t gs_stride, int ld_w, int ld_g, float g_scale, int tiles_m, int tiles_n, int rowch) {
+    int64_t gs_stride, int ld_w, int ld_g, float g_scale, int tiles_m, int tiles_n, int rowch, int rowch_a) {
     constexpr int NW = 4, RS = 128, CS = SPLIT_CS, NTHR = NW * 64, NR = 2;
+    constexpr bool ARES = MODE == 2, MULTI = MODE != 0;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_b[];
-    const int ROWB = rowch * 16;                 // bytes per row/column of one piece image
-    const int PS = RS * ROWB;                    // piece stride (RS == CS)
+    const int ROWB = rowch * 16;                 // bytes per row of one G piece image (an odd number of 16-byte chunks)
+    const int ROWA = rowch_a * 16;               // the same for A (ARES: the whole sequence; else = ROWB)
+    const int PS = RS * ROWB, PSA = CS * ROWA;   // piece strides
     unsigned char* sG = smem_b;                  // [3][RS][ROWB]
-    unsigned char* sA = smem_b + 3 * PS;         // [3][CS][ROWB]
-    float* sBias = reinterpret_cast<float*>(sA + 3 * PS);  // [SPLIT_NQ][RS]
-    float* red = sBias + SPLIT_NQ * RS;                    // [2][NW]
+    unsigned char* sA = smem_b + 3 * PS;         // [3][CS][ROWA]
+    float* sBias = reinterpret_cast<float*>(sA + 3 * PSA);  // [SPLIT_NQ][RS]
+    float* red = sBias + SPLIT_NQ * RS;                     // [2][NW]
 
-    // ---- XCD-aware walk over (job, sample slot, tile row, tile column, chunk) ----------------------------------------
-    const int ntile = tiles_m * tiles_n;
+    // ---- XCD-aware walk: groups (job, sample slot, column tile) round-robin over the XCD's workgroups; inside a group
+    // the row tiles, inside a tile the chunks.  ARES: step c = -1 of a group stages its A slice. --------------------------
     const int xcd = blockIdx.x & 7;
     const int nbx = gridDim.x >> 3;
     const int nsx = (B - xcd + 7) / 8;
@@ -538,14 +546,28 @@ __global__ void __launch_bounds__(256, 2) linear_gs_split_kernel(
     struct Cur {
         int job, s, tm, tn, c;
     };
-    const int d_s = nbx / ntile, d_tm = (nbx % ntile) / tiles_n, d_tn = nbx % tiles_n;
+    // ARES: the unit of distribution is the group (stride nbx over (job, s, tn)); otherwise the tile (stride nbx over
+    // (job, s, tm, tn): the workgroups of an XCD then work on the same few samples at the same time and meet in L2)
+    const int ntile = tiles_m * tiles_n;
+    const int d_s = ARES ? nbx / tiles_n : nbx / ntile;
+    const int d_tm = ARES ? 0 : (nbx % ntile) / tiles_n;
+    const int d_tn = nbx % tiles_n;
     auto next = [&](Cur x) {
+        if (ARES && x.c < 0) { x.c = 0; return x; }
         if (MULTI && x.c + 1 < nch) { ++x.c; return x; }
         x.c = 0;
-        x.tn += d_tn;
-        if (x.tn >= tiles_n) { x.tn -= tiles_n; ++x.tm; }
-        x.tm += d_tm;
-        if (x.tm >= tiles_m) { x.tm -= tiles_m; ++x.s; }
+        if constexpr (ARES) {
+            if (x.tm + 1 < tiles_m) { ++x.tm; return x; }
+            x.tm = 0;
+            x.c = -1;
+            x.tn += d_tn;
+            if (x.tn >= tiles_n) { x.tn -= tiles_n; ++x.s; }
+        } else {
+            x.tn += d_tn;
+            if (x.tn >= tiles_n) { x.tn -= tiles_n; ++x.tm; }
+            x.tm += d_tm;
+            if (x.tm >= tiles_m) { x.tm -= tiles_m; ++x.s; }
+        }
         x.s += d_s;
         while (x.s >= nsx && x.job < jobs.n) { x.s -= nsx; ++x.job; }  // job == jobs.n: past the last item
         return x;
@@ -554,9 +576,14 @@ __global__ void __launch_bounds__(256, 2) linear_gs_split_kernel(
     {
         const int w = blockIdx.x >> 3;
         cur.job = 0;
-        cur.c = 0;
-        cur.s = w / ntile;
-        cur.tm = (w % ntile) / tiles_n;
+        cur.c = ARES ? -1 : 0;
+        if constexpr (ARES) {
+            cur.tm = 0;
+            cur.s = w / tiles_n;
+        } else {
+            cur.s = w / ntile;
+            cur.tm = (w % ntile) / tiles_n;
+        }
         cur.tn = w % tiles_n;
         while (cur.s >= nsx && cur.job < jobs.n) { cur.s -= nsx; ++cur.job; }
     }
@@ -573,17 +600,23 @@ __global__ void __launch_bounds__(256, 2) linear_gs_split_kernel(
     // the sequence end are loaded out of range = zeros; single-chunk mode zeroes them once, below)
     auto chunk_kc = [&](int c) { const int len = min(SPLIT_TC, T - c * SPLIT_TC); return (len + 15) >> 4; };
     auto chunk_nq = [&](int c) { return MULTI ? 4 * chunk_kc(c) : (T + 3) >> 2; };
+    const int nq_all = 4 * ((T + 15) >> 4);  // ARES: 4-step groups of the whole (k-step padded) sequence
 
-    // staging tasks of a chunk: task = (4-step group tq, 4 adjacent columns cgp*4..+3); [0, Gpad) are G's, then A's;
+    // staging tasks of a step: task = (4-step group tq, 4 adjacent columns cgp*4..+3); [0, Gpad) are G's, then A's;
     // a wave's 64 tasks are all of one kind (Gpad is a multiple of 64): the descriptor is chosen with scalar code.
-    // A cursor past the last item fetches nothing (empty descriptor), so there is no branch around the loads.
+    // ARES: an A step has only A tasks (of the whole sequence), a G step only G tasks.
+    auto tasks_g = [&](int c) { return (ARES && c < 0) ? 0 : 32 * chunk_nq(c); };
+    auto quads_a = [&](int c) { return ARES ? (c < 0 ? nq_all : 0) : chunk_nq(c); };
+
+    // A cursor past the last group fetches nothing (empty descriptor), so there is no branch around the loads.
     f32x4 rq[2][NR][4];
     auto prefetch = [&](f32x4 (&r)[NR][4], const Cur& x) {
         const bool valid = x.job < jobs.n;
         const int job = valid ? x.job : 0;
         const int64_t b = x.s * 8 + xcd;
-        const int nq = chunk_nq(x.c), t0 = x.c * SPLIT_TC;
-        const int Gpad = (32 * nq + 63) & ~63;
+        const int nqg = tasks_g(x.c) >> 5, nqa = quads_a(x.c);
+        const int t0 = (x.c < 0 ? 0 : x.c) * SPLIT_TC;
+        const int Gpad = (32 * nqg + 63) & ~63;
 #pragma unroll
         for (int k = 0; k < NR; ++k) {
             const int wbase = wave * 64 + k * NTHR;
@@ -597,7 +630,7 @@ __global__ void __launch_bounds__(256, 2) linear_gs_split_kernel(
             const int col = (isG ? x.tm * RS : x.tn * CS) + (idx & 31) * 4;
             const int ld = isG ? ld_g : in_f;
             const int dim = isG ? out_f : in_f;
-            unsigned off = (tq < nq && col < dim) ? (unsigned)((t0 + 4 * tq) * ld + col) * 4u : OOB;
+            unsigned off = (tq < (isG ? nqg : nqa) && col < dim) ? (unsigned)((t0 + 4 * tq) * ld + col) * 4u : OOB;
             const unsigned rowb = (unsigned)ld * 4u;
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
@@ -607,8 +640,8 @@ __global__ void __launch_bounds__(256, 2) linear_gs_split_kernel(
         }
     };
     auto stage = [&](const f32x4 (&r)[NR][4], const Cur& x) {  // prefetched registers -> three bf16 images in LDS
-        const int nq = chunk_nq(x.c);
-        const int Gpad = (32 * nq + 63) & ~63;
+        const int nqg = tasks_g(x.c) >> 5, nqa = quads_a(x.c);
+        const int Gpad = (32 * nqg + 63) & ~63;
 #pragma unroll
         for (int k = 0; k < NR; ++k) {
             const int wbase = wave * 64 + k * NTHR;
@@ -617,7 +650,7 @@ __global__ void __launch_bounds__(256, 2) linear_gs_split_kernel(
             const int tq = idx >> 5;
             const int cgp = idx & 31;
             const int left = isG ? out_f - (x.tm * RS + cgp * 4) : in_f - (x.tn * CS + cgp * 4);
-            if (tq < nq) {
+            if (tq < (isG ? nqg : nqa)) {
                 f32x4 v[4];
 #pragma unroll
                 for (int i = 0; i < 4; ++i) v[i] = mask4(r[k][i], left);
@@ -627,15 +660,17 @@ __global__ void __launch_bounds__(256, 2) linear_gs_split_kernel(
                     *reinterpret_cast<f32x4*>(sBias + tq * RS + cgp * 4) = (v[0] + v[1]) + (v[2] + v[3]);
                 }
                 // column 4*cgp+e of the tile -> position e*32 + cgp (slot cgp of MFMA block e), for G and for A
-                unsigned char* dst = (isG ? sG : sA) + cgp * ROWB + tq * 8;
+                const int rowb = isG ? ROWB : ROWA;
+                const int pstride = isG ? PS : PSA;
+                unsigned char* dst = (isG ? sG : sA) + cgp * rowb + tq * 8;
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
                     float x0 = v[0][e], x1 = v[1][e], x2 = v[2][e], x3 = v[3][e];
-                    unsigned char* d = dst + e * 32 * ROWB;
+                    unsigned char* d = dst + e * 32 * rowb;
 #pragma unroll
                     for (int p = 0; p < 3; ++p) {
                         const u32x2 w = {pack_bf16_rn(x0, x1), pack_bf16_rn(x2, x3)};
-                        *reinterpret_cast<u32x2*>(d + p * PS) = w;
+                        *reinterpret_cast<u32x2*>(d + p * pstride) = w;
                         if (p < 2) {
                             x0 = rest_lo(x0, w[0]);
                             x1 = rest_hi(x1, w[0]);
@@ -670,34 +705,33 @@ __global__ void __launch_bounds__(256, 2) linear_gs_split_kernel(
     int parity = 0;
     f32x16 acc[4];
     float bsum = 0.f;
-    // one chunk: stage its operands (fetched two chunks ago), fetch the chunk two ahead into the freed registers,
-    // contract; on an item's last chunk store the unit and publish the tile's squared norm
+    // one step: stage its operands (fetched two steps ago), fetch the step two ahead into the freed registers,
+    // contract; on a tile's last chunk store the unit and publish the tile's squared norm
     auto step = [&](f32x4 (&r)[NR][4]) {
         const int m0 = cur.tm * RS, n0 = cur.tn * CS;
         const int64_t b = cur.s * 8 + xcd;
-        if (cur.c == 0) {
+#ifdef DPK_K1_STAMPS
+        st_last = __builtin_amdgcn_s_memtime();
+        ++st_items;
+#endif
+        // ARES, step c = -1: the group's A slice.  Every wave has passed the previous tile's closing barrier, so nobody
+        // reads A any more; the first G step's barrier publishes it.  Same stage / prefetch code, nothing else.
+        const bool astep = ARES && cur.c < 0;
+        if (!astep && cur.c == 0) {
 #pragma unroll
             for (int j = 0; j < 4; ++j)
 #pragma unroll
                 for (int q = 0; q < 16; ++q) acc[j][q] = 0.f;
             bsum = 0.f;
         }
-#ifdef DPK_K1_STAMPS
-        st_last = __builtin_amdgcn_s_memtime();
-        ++st_items;
-#if DPK_K1_STAMPS == 2
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        STAMP(7);
-#endif
-#endif
         if (!(DPK_K1_ABL & 4)) stage(r, cur);
         STAMP(0);
-        lds_only_barrier();
+        if (!astep) lds_only_barrier();
         STAMP(1);
         // the first k-step's operands are requested before the prefetch is issued: their LDS latency passes under the
         // prefetch's address arithmetic, and each later k-step's under the tail of the previous one's MFMAs
         const unsigned char* pg = sG + (mr * 32 + l31) * ROWB + lh * 16;
-        const unsigned char* pa = sA + l31 * ROWB + lh * 16;
+        const unsigned char* pa = sA + l31 * ROWA + ((ARES ? cur.c * (SPLIT_TC / 8) : 0) + lh) * 16;
         bf16x8 g[3], a[3][4];
         auto load_ops = [&]() {
 #pragma unroll
@@ -705,14 +739,14 @@ __global__ void __launch_bounds__(256, 2) linear_gs_split_kernel(
 #pragma unroll
             for (int q = 0; q < 3; ++q)
 #pragma unroll
-                for (int j = 0; j < 4; ++j) a[q][j] = *reinterpret_cast<const bf16x8*>(pa + q * PS + j * 32 * ROWB);
+                for (int j = 0; j < 4; ++j) a[q][j] = *reinterpret_cast<const bf16x8*>(pa + q * PSA + j * 32 * ROWA);
             pg += 32;
             pa += 32;
         };
-        load_ops();
-        prefetch(r, n2);  // ahead of this item's stores in the vector-memory pipe
+        if (!astep) load_ops();
+        prefetch(r, n2);  // ahead of this tile's stores in the vector-memory pipe
         STAMP(2);
-        if (!(DPK_K1_ABL & 2)) {
+        if (!astep && !(DPK_K1_ABL & 2)) {
             const int kc = chunk_kc(cur.c);
             for (int ks = 0; ks < kc; ++ks) {
 #pragma unroll
@@ -735,7 +769,8 @@ __global__ void __launch_bounds__(256, 2) linear_gs_split_kernel(
             }
         }
         STAMP(3);
-        if (!MULTI || cur.c == nch - 1) {
+        if (astep) {
+        } else if (!MULTI || cur.c == nch - 1) {
             // stores: accumulator row slot m = (q&3) + 8*(q>>2) + 4*lh of MFMA block mr is feature m0 + 4*m + mr; rows
             // >= out_f fall outside the descriptor, columns >= ld_w get the out-of-range offset
             float sq = 0.f;
@@ -766,7 +801,7 @@ __global__ void __launch_bounds__(256, 2) linear_gs_split_kernel(
             STAMP(4);
             sq = wave_sum(sq);
             if (lane == 0) red[parity * NW + wave] = sq;
-            lds_only_barrier();  // every wave is done with this item's images; red[parity] is complete
+            lds_only_barrier();  // every wave is done with this tile's images; red[parity] is complete
             {
                 float tot = 0.f;
 #pragma unroll
@@ -910,22 +945,26 @@ int k1_launch(const float* const* A, const float* const* G, float* const* GSw, f
         if (mode != 0) {
             // split-operand kernel: exact fp32 products on the bf16 matrix pipe, any sequence length; 128 x 128 tiles,
             // two workgroups of 4 waves per CU
-            const int64_t items = ((int64_t)(B + 7) / 8) * 8 * tiles_m * slot_cols * n_jobs;
+            // 32 < T <= 48: the A slice of a (sample, column tile) group stays in LDS for all its row tiles, and a
+            // workgroup takes whole groups (no more workgroups than groups); otherwise it takes tiles
+            const int kmode = T > PERSIST_MAX_T ? 1 : T > SPLIT_TC ? 2 : 0;
+            const int64_t units = ((int64_t)(B + 7) / 8) * 8 * slot_cols * n_jobs * (kmode == 2 ? 1 : tiles_m);
             int64_t want = 2 * (int64_t)dpk_cu_count();
-            if (want > items) want = items;
+            if (want > units) want = units;
             const dim3 pgrid((unsigned)((want + 7) / 8 * 8));
             const int kcmax = T >= 17 ? 2 : 1;
             const int rowch = 2 * kcmax + 1;
-            const size_t lds = (size_t)3 * (128 + SPLIT_CS) * rowch * 16 + (SPLIT_NQ * 128 + 2 * 4) * sizeof(float);
-            const bool multi = T > SPLIT_TC;
-#define DPK_K1_SPLIT_TERMS(MULTIV)                                                                               \
-    do {                                                                                                         \
-        if (mode == 6) DPK_K1_PERSIST_GO(256, (linear_gs_split_kernel<6, MULTIV>), lds, slot_cols, rowch);       \
-        else if (mode == 9) DPK_K1_PERSIST_GO(256, (linear_gs_split_kernel<9, MULTIV>), lds, slot_cols, rowch);  \
-        else DPK_K1_PERSIST_GO(256, (linear_gs_split_kernel<8, MULTIV>), lds, slot_cols, rowch);                 \
+            const int rowch_a = kmode == 2 ? 2 * ((T + 15) / 16) + 1 : rowch;
+            const size_t lds = (size_t)3 * 128 * (rowch + rowch_a) * 16 + (SPLIT_NQ * 128 + 2 * 4) * sizeof(float);
+#define DPK_K1_SPLIT_TERMS(MODEV)                                                                                 \
+    do {                                                                                                          \
+        if (mode == 6) DPK_K1_PERSIST_GO(256, (linear_gs_split_kernel<6, MODEV>), lds, slot_cols, rowch, rowch_a); \
+        else if (mode == 9) DPK_K1_PERSIST_GO(256, (linear_gs_split_kernel<9, MODEV>), lds, slot_cols, rowch, rowch_a); \
+        else DPK_K1_PERSIST_GO(256, (linear_gs_split_kernel<8, MODEV>), lds, slot_cols, rowch, rowch_a);          \
     } while (0)
-            if (multi) DPK_K1_SPLIT_TERMS(true);
-            else DPK_K1_SPLIT_TERMS(false);
+            if (kmode == 2) DPK_K1_SPLIT_TERMS(2);
+            else if (kmode == 1) DPK_K1_SPLIT_TERMS(1);
+            else DPK_K1_SPLIT_TERMS(0);
 #undef DPK_K1_SPLIT_TERMS
             return dpk_launch_status();
         }
