@@ -41,6 +41,8 @@ sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6300 achievable
 MFMA_F32_PEAK_TFLOPS = 157.3
+MFMA_BF16_PEAK_TFLOPS = 2516.6  # dense; K1 at T > 32 forms each fp32 product from 6 bf16 partial products on this pipe
+K1_SPLIT_TERMS = 6
 
 
 def parse(argv=None):
@@ -349,20 +351,28 @@ def run_config(cfg, ctx, args, steps, warmup, batch=None, want_hot=True):
     k1_bytes = B * (4.0 * n_params + io_bytes)  # per step: every gradient element written once + operand reads
     k1_gbs = k1_bytes / (k1_total_ms * 1e-3) / 1e9
     k1_tf = B * flops / (k1_total_ms * 1e-3) / 1e12
-    ridge = MFMA_F32_PEAK_TFLOPS * 1e12 / (HBM_PEAK_GBS * 1e9)
+    # K1's large-layer kernel: fp32 MFMA up to 32 steps; beyond, fp32 products as K1_SPLIT_TERMS exact bf16 partial
+    # products (fp32 accumulate) on the bf16 pipe, whose peak in ALGORITHMIC fp32 flops is the bf16 peak / terms
+    T_seq = max(workloads.CONFIGS[p.name]["T"] for p in parts)
+    split = T_seq > 32 and os.environ.get("DPK_K1_MFMA", "") != "f32"
+    mfma_peak = MFMA_BF16_PEAK_TFLOPS / K1_SPLIT_TERMS if split else MFMA_F32_PEAK_TFLOPS
+    ridge = mfma_peak * 1e12 / (HBM_PEAK_GBS * 1e9)
     ai = B * flops / k1_bytes
     traffic = pmc_traffic(cfg, B, parts)
     roof = {"bound": "hbm" if ai < ridge else "mfma",
-            "kernel": "linear_gs_persist_kernel / linear_gs_kernel (K1: per-sample-gradient contraction, every Linear "
-                      "layer of one step)",
-            "achieved": k1_gbs if ai < ridge else k1_tf, "peak": HBM_PEAK_GBS if ai < ridge else MFMA_F32_PEAK_TFLOPS,
+            "kernel": ("linear_gs_split_kernel" if split else "linear_gs_persist_wide_kernel") + " / linear_gs_kernel "
+                      "(K1: per-sample-gradient contraction, every Linear layer of one step)",
+            "arithmetic": (f"fp32 in/out, fp32 accumulate; products = {K1_SPLIT_TERMS} of the 9 exact partial products of a "
+                           "3-way bf16 split (v_mfma_f32_32x32x16_bf16); dropped < 2^-26 of a product" if split else
+                           "fp32 (v_mfma_f32_32x32x2_f32)"),
+            "achieved": k1_gbs if ai < ridge else k1_tf, "peak": HBM_PEAK_GBS if ai < ridge else mfma_peak,
             "unit": "GB/s" if ai < ridge else "TFLOP/s",
-            "frac": (k1_gbs / HBM_PEAK_GBS) if ai < ridge else (k1_tf / MFMA_F32_PEAK_TFLOPS),
+            "frac": (k1_gbs / HBM_PEAK_GBS) if ai < ridge else (k1_tf / mfma_peak),
             "traffic": traffic.get("k1"), "traffic_source": traffic.get("source"),
             "ms_per_step": k1_total_ms, "launches_per_step": k1_launches,
             "avg_launch_ms": k1_total_ms / max(k1_launches, 1), "bytes_per_step": k1_bytes,
             "hbm_GBs": k1_gbs, "hbm_frac": k1_gbs / HBM_PEAK_GBS, "tflops": k1_tf,
-            "mfma_frac": k1_tf / MFMA_F32_PEAK_TFLOPS, "flop_per_byte": ai}
+            "mfma_frac": k1_tf / mfma_peak, "mfma_peak_tflops": mfma_peak, "flop_per_byte": ai}
     k7_ms = k7.mean_ms()
     k7_launches = len(k7.events) / n_timed
     k7_bytes = sum(4.0 * p.gsm.arena.P * p.B for p in parts) / max(k7_launches, 1)  # arena read once per step
