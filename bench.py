@@ -125,31 +125,27 @@ def dry_run(args, rank, world):
 # ---- kernel timing ----------------------------------------------------------------------------------------------
 
 class KernelTimer:
-    """Wraps _native entry points (one kernel family) with HIP events recorded on the launch stream.  Wrapped entry
-    points may call each other (the single-layer K1 call forwards strided operands to the grouped one): only the
-    outermost call is timed."""
+    """Brackets the C-ABI entry points of one kernel family with HIP events recorded on the launch stream.  The ctypes
+    functions of the loaded library are wrapped, not the Python wrappers around them: the host-side argument
+    marshalling of a call must not sit between the two records (with an idle GPU the first event fires at once and
+    the interval would include it — for the small-batch configs that was most of the reading)."""
 
-    def __init__(self, native, *names):
-        self.native, self.names = native, names
+    def __init__(self, native, *symbols):
+        self.native, self.symbols = native, symbols
         self.events = []
         self.enabled = False
-        self.depth = 0
-        for name in names:
-            if hasattr(native, name):
-                setattr(native, name, self._wrap(getattr(native, name)))
+        lib = native.load()
+        for name in symbols:
+            setattr(lib, name, self._wrap(getattr(lib, name)))  # instance attribute shadows the ctypes function
 
     def _wrap(self, orig):
-        def call(*a, **k):
-            if not self.enabled or self.depth:
-                return orig(*a, **k)
+        def call(*a):
+            if not self.enabled:
+                return orig(*a)
             e0 = torch.cuda.Event(enable_timing=True)
             e1 = torch.cuda.Event(enable_timing=True)
             e0.record()  # torch's current stream == the stream _native launches on
-            self.depth += 1
-            try:
-                r = orig(*a, **k)
-            finally:
-                self.depth -= 1
+            r = orig(*a)
             e1.record()
             self.events.append((e0, e1))
             return r
@@ -172,8 +168,9 @@ _TIMERS = {}
 
 def timers(native):
     if not _TIMERS:
-        _TIMERS["k7"] = KernelTimer(native, "clip_reduce_noise", "clip_reduce")
-        _TIMERS["k1"] = KernelTimer(native, "linear_grad_sample", "linear_grad_sample_group", "linear_grad_sample_multi")
+        _TIMERS["k7"] = KernelTimer(native, "dpk_clip_reduce_noise", "dpk_clip_reduce")
+        _TIMERS["k1"] = KernelTimer(native, "dpk_linear_grad_sample", "dpk_linear_grad_sample_group",
+                                    "dpk_linear_grad_sample_multi")
     return _TIMERS["k1"], _TIMERS["k7"]
 
 
@@ -252,7 +249,17 @@ class Part:
         self.graphed = None
         if not args.eager and len(self.chunks) == 1:
             from dp_timeautodiff_amd.graphed import GraphedDPStep
-            self.graphed = GraphedDPStep(self.gsm, self.opt, lambda: wl.loss_fn(self.gsm, 0, B), warmup=2).capture()
+            try:
+                self.graphed = GraphedDPStep(self.gsm, self.opt, lambda: wl.loss_fn(self.gsm, 0, B), warmup=2).capture()
+            except Exception as e:  # noqa: BLE001
+                if world == 1:
+                    raise
+                # a multi-rank capture that the collective library refuses fails on every rank alike: say so and time
+                # eager steps instead of printing nothing (the line's config.launch then reads "eager")
+                print(f"[bench] rank {ctx['rank']}: graph capture of the data-parallel step failed ({type(e).__name__}: "
+                      f"{e}); falling back to eager launches", file=sys.stderr, flush=True)
+                torch.cuda.synchronize()
+                self.graphed = None
 
     def eager_step(self):
         opt, wl = self.opt, self.wl
@@ -560,10 +567,17 @@ def hot_path(native, gsm, opt, wl, chunks, steps):
     for _ in range(3):
         replay()
     torch.cuda.synchronize()
+    # the launches of one pass as a hipGraph: at the small-batch configs the host cannot issue a dozen launches in the
+    # 0.1 ms they take, and the reading would be the host's
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph):
+        replay()
+    graph.replay()
+    torch.cuda.synchronize()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()
     for _ in range(steps):
-        replay()
+        graph.replay()
     e1.record()
     torch.cuda.synchronize()
     ms = e0.elapsed_time(e1) / steps
@@ -571,7 +585,7 @@ def hot_path(native, gsm, opt, wl, chunks, steps):
     bytes_ps = 8.0 * wl.n_params + wl.io_bytes_per_sample
     sps = Bc / (ms * 1e-3)
     return {"what": "K1..K7 only (per-sample grads from resident activations/backprops -> norms -> clip -> sum -> "
-                    "noise -> scale), one physical chunk", "batch": Bc, "ms": ms, "samples_per_s": sps,
+                    "noise -> scale), one physical chunk, replayed as a hipGraph", "batch": Bc, "ms": ms, "samples_per_s": sps,
             "bytes_per_sample": bytes_ps, "hbm_GBs": sps * bytes_ps / 1e9, "hbm_frac": sps * bytes_ps / 1e9 / HBM_PEAK_GBS,
             "mfma_tflops": sps * wl.flops_per_sample / 1e12,
             "mfma_frac": sps * wl.flops_per_sample / 1e12 / MFMA_F32_PEAK_TFLOPS}

@@ -29,6 +29,7 @@ EXPORTS = {
                                        c_int, c_int, c_int, c_int, c_int64, c_int, c_float, c_void_p]),
     "dpk_linear_grad_sample_group": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_int64,
                                              c_int, c_int, c_int, c_int, c_int64, c_int, c_int, c_float, c_void_p]),
+    "dpk_linear_grad_sample_multi": (c_int, [c_void_p, c_int, c_void_p, c_int64, c_int, c_int64, c_float, c_void_p]),
     "dpk_embedding_grad_sample": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int,
                                           c_int, c_int, c_int, c_int, c_int64, c_float, c_void_p]),
     "dpk_layernorm_grad_sample": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int,
@@ -211,6 +212,59 @@ def linear_grad_sample_group(jobs, part: torch.Tensor, g_scale: float, ld_w: Opt
     rc = load().dpk_linear_grad_sample_group(pa, pg, pw, pb, slots, n, _ptr(part), part.stride(0), B, T, in_f, out_f,
                                              w0.stride, ld_w, ld_g, float(g_scale), _stream())
     _check(rc, "dpk_linear_grad_sample_group")
+
+
+K1_MULTI_MAX_JOBS = 32
+K1_MULTI_MAX_T = 48
+
+
+class _K1Job(ctypes.Structure):  # dpk_k1_job (include/dpk.h)
+    _fields_ = [("A", c_void_p), ("G", c_void_p), ("GSw", c_void_p), ("GSb", c_void_p), ("slot0", c_int), ("T", c_int),
+                ("in_features", c_int), ("out_features", c_int), ("ld_w", c_int), ("ld_g", c_int)]
+
+
+def multi_ok(A, G, ld_w: int) -> bool:
+    """Can this layer's contraction join a dpk_linear_grad_sample_multi launch?"""
+    return (A.dim() == 3 and G.dim() == 3 and A.is_contiguous() and _rows_ld(G) is not None
+            and A.shape[1] <= K1_MULTI_MAX_T and ld_w % 4 == 0)
+
+
+def linear_grad_sample_multi(jobs, part: torch.Tensor, g_scale: float):
+    """jobs: list of (A, G, gs_w, gs_b or None, slot0, ld_w) of ANY shapes sharing B and the arena; launches of up to
+    K1_MULTI_MAX_JOBS layers each (dpk_linear_grad_sample_multi)."""
+    if not jobs:
+        return
+    _req(part, "normsq_part")
+    B = jobs[0][0].shape[0]
+    w0 = jobs[0][2]
+    if part.shape[0] < B or part.dim() != 2 or part.stride(1) != 1:
+        raise DpkError("partial buffer has fewer rows than the batch")
+    recs = []
+    for A, G, gs_w, gs_b, slot0, ld_w in jobs:
+        _req(A, "A"); _req(G, "G"); _req(gs_w.base, "arena")
+        if A.dim() != 3 or G.dim() != 3 or not A.is_contiguous() or A.shape[0] != B or G.shape[:2] != A.shape[:2]:
+            raise DpkError("every job needs A [B,T,in] contiguous and G [B,T,out] with one common B")
+        ld_g = _rows_ld(G)
+        in_f, out_f = A.shape[2], G.shape[2]
+        if ld_g is None:
+            raise DpkError("G must be [B,T,out] rows of one stride (contiguous, or a column block)")
+        if ld_w < in_f or gs_w.numel != ld_w * out_f or (gs_b is not None and gs_b.numel != out_f):
+            raise DpkError("grad-sample window does not match the layer shape")
+        if gs_w.base.shape[0] < B or gs_w.stride != w0.stride or gs_w.base.data_ptr() != w0.base.data_ptr():
+            raise DpkError("arena has fewer rows than the batch / jobs live in different arenas")
+        if gs_b is not None and gs_b.base.data_ptr() != gs_w.base.data_ptr():
+            raise DpkError("weight and bias windows must live in the same arena")
+        recs.append(_K1Job(_ptr(A), _ptr(G), gs_w.ptr, None if gs_b is None else gs_b.ptr, int(slot0), A.shape[1],
+                           in_f, out_f, int(ld_w), int(ld_g)))
+    if B == 0:
+        return
+    lib = load()
+    for i in range(0, len(recs), K1_MULTI_MAX_JOBS):
+        chunk = recs[i:i + K1_MULTI_MAX_JOBS]
+        arr = (_K1Job * len(chunk))(*chunk)
+        rc = lib.dpk_linear_grad_sample_multi(ctypes.cast(arr, c_void_p), len(chunk), _ptr(part), part.stride(0), B,
+                                              w0.stride, float(g_scale), _stream())
+        _check(rc, "dpk_linear_grad_sample_multi")
 
 
 def embedding_grad_sample(idx, G, gs: FlatView, V: int, part: torch.Tensor, slot0: int, g_scale: float):

@@ -463,6 +463,199 @@ __global__ void __launch_bounds__(512) linear_gs_persist_wide_kernel(
     while (more) do_item();
 }
 
+// ---- persistent wide-unit kernel over layers of DIFFERENT shapes (small batches) ---------------------------------------
+// At the reference's own batch size (B ~ 50) a layer's launch is a handful of items per CU: 12 launches per step each
+// pay a ramp and a tail.  All layers whose arena rows allow 16-byte stores go through ONE launch instead: the job table
+// carries each layer's shape, the item walk is flat over (job, sample, tile) with one 32-bit division per item, and the
+// per-item constants (T, strides, LDS split) are scalar loads from the table.  Per tile the arithmetic is exactly that
+// of linear_gs_persist_wide_kernel (same k order, same bias pairing): results equal per-layer launches bit for bit.
+struct K1Shape {
+    int T, in_f, out_f, ld_w, ld_g, tiles_m, tiles_n, slot_cols, slot_mul, tile0;  // tile0: tiles of the jobs before
+};
+struct K1MultiJobs {
+    const float* A[DPK_K1_MULTI_MAX_JOBS];
+    const float* G[DPK_K1_MULTI_MAX_JOBS];
+    float* W[DPK_K1_MULTI_MAX_JOBS];
+    float* Bi[DPK_K1_MULTI_MAX_JOBS];  // nullable
+    int slot0[DPK_K1_MULTI_MAX_JOBS];
+    K1Shape sh[DPK_K1_MULTI_MAX_JOBS];
+    int n, tiles_total;
+};
+
+template <int NG, int NA>
+__global__ void __launch_bounds__(512) linear_gs_multi_kernel(const K1MultiJobs jobs, float* __restrict__ normsq_part,
+                                                             int64_t part_stride, int B, int64_t gs_stride,
+                                                             float g_scale) {
+    constexpr int NW = 8, RS = 128, CS = 256, NTHR = NW * 64;
+    constexpr int R4 = RS / 4, C4 = CS / 4;
+    extern __shared__ __attribute__((aligned(16))) float smem[];  // red[2][NW], [Tp][RS] G, [Tp][CS] A, 2 pad rows
+    float* red = smem;
+    float* sG = smem + 2 * NW;
+
+    const int xcd = blockIdx.x & 7;
+    const int nbx = gridDim.x >> 3;
+    const int nsx = (B - xcd + 7) / 8;               // samples on this XCD: b = 8 s + xcd
+    const int total = nsx * jobs.tiles_total;        // items of this XCD, job-major: job j owns nsx * ntile_j of them
+    struct Item {
+        int it, job, s, tm, tn;
+    };
+    auto locate = [&](int it, int job) {  // job only moves forward
+        Item x;
+        x.it = it;
+        if (it >= total) { x.job = jobs.n; x.s = x.tm = x.tn = 0; return x; }
+        while (job + 1 < jobs.n && it >= nsx * jobs.sh[job + 1].tile0) ++job;
+        const K1Shape& h = jobs.sh[job];
+        const int local = it - nsx * h.tile0, ntile = h.tiles_m * h.tiles_n;
+        x.job = job;
+        x.s = local / ntile;
+        const int tile = local - x.s * ntile;
+        x.tm = tile / h.tiles_n;
+        x.tn = tile - x.tm * h.tiles_n;
+        return x;
+    };
+    Item cur = locate(blockIdx.x >> 3, 0);
+    if (nsx <= 0 || cur.job >= jobs.n) return;  // uniform
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int l31 = lane & 31;
+    const int lh = lane >> 5;
+    const int mr = wave >> 1, cg = wave & 1;
+
+    f32x4 rg[NG], ra[NA];
+    auto prefetch = [&](const Item& x) {
+        const K1Shape h = jobs.sh[x.job];
+        const int64_t b = x.s * 8 + xcd;
+        const auto rsG = make_rsrc(jobs.G[x.job] + b * h.T * h.ld_g, ((int64_t)(h.T - 1) * h.ld_g + h.out_f) * 4);
+        const auto rsA = make_rsrc(jobs.A[x.job] + b * h.T * h.in_f, (int64_t)h.T * h.in_f * 4);
+#pragma unroll
+        for (int k = 0; k < NG; ++k) {
+            const int idx = tid + k * NTHR;
+            const int t = idx / R4, col = x.tm * RS + (idx - t * R4) * 4;
+            const unsigned off = (t < h.T && col < h.out_f) ? (unsigned)(t * h.ld_g + col) * 4u : OOB;
+            rg[k] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsG, off, 0, 0));
+        }
+#pragma unroll
+        for (int k = 0; k < NA; ++k) {
+            const int idx = tid + k * NTHR;
+            const int t = idx / C4, col = x.tn * CS + (idx - t * C4) * 4;
+            const unsigned off = (t < h.T && col < h.in_f) ? (unsigned)(t * h.in_f + col) * 4u : OOB;
+            ra[k] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsA, off, 0, 0));
+        }
+    };
+    auto stage = [&](const Item& x) {
+        const K1Shape h = jobs.sh[x.job];
+        const int Tp = (h.T + 1) & ~1;
+        float* sA = sG + Tp * RS;
+        const int totG = Tp * R4, totA = Tp * C4;
+#pragma unroll
+        for (int k = 0; k < NG; ++k) {
+            const int idx = tid + k * NTHR;
+            const int left = h.out_f - (x.tm * RS + (idx % R4) * 4);
+            if (idx < totG) *reinterpret_cast<f32x4*>(sG + idx * 4) = mask4(rg[k], left) * g_scale;
+        }
+#pragma unroll
+        for (int k = 0; k < NA; ++k) {
+            const int idx = tid + k * NTHR;
+            const int left = h.in_f - (x.tn * CS + (idx % C4) * 4);
+            if (idx < totA) *reinterpret_cast<f32x4*>(sA + idx * 4) = mask4(ra[k], left);
+        }
+    };
+
+    prefetch(cur);
+    int parity = 0;
+    bool more = true;
+    auto do_item = [&]() {
+        stage(cur);
+        lds_only_barrier();
+        const Item nxt = locate(cur.it + nbx, cur.job);
+        const bool has_next = nxt.job < jobs.n;
+        if (has_next) prefetch(nxt);
+
+        const K1Shape h = jobs.sh[cur.job];
+        const int Tp = (h.T + 1) & ~1, ksteps = Tp >> 1;
+        const float* sA = sG + Tp * RS;
+        const int m0 = cur.tm * RS, n0 = cur.tn * CS;
+        const int64_t b = cur.s * 8 + xcd;
+        const bool live = (m0 + mr * 32 < h.out_f) && (n0 + cg * 128 < h.in_f);
+        f32x16 acc[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
+        float bsum = 0.f;
+        if (live) {
+            const float* pg = sG + lh * RS + mr * 32 + l31;
+            const float* pa = sA + lh * CS + cg * 128 + 4 * l31;
+            float a_nx = pg[0];
+            f32x4 b_nx = *reinterpret_cast<const f32x4*>(pa);
+            for (int q = 0; q < ksteps; ++q) {
+                const float a = a_nx;
+                const f32x4 bv = b_nx;
+                pg += 2 * RS;
+                pa += 2 * CS;
+                a_nx = *pg;  // one past the end on the last step: readable padding, never used
+                b_nx = *reinterpret_cast<const f32x4*>(pa);
+                acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, bv[0], acc[0], 0, 0, 0);
+                acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, bv[1], acc[1], 0, 0, 0);
+                acc[2] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, bv[2], acc[2], 0, 0, 0);
+                acc[3] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, bv[3], acc[3], 0, 0, 0);
+                bsum += a;
+            }
+        }
+        float sq = 0.f;
+        {
+            const auto rsW = make_rsrc(jobs.W[cur.job] + b * gs_stride, live ? (int64_t)h.out_f * h.ld_w * 4 : 0);
+            const int col = n0 + cg * 128 + 4 * l31;
+            unsigned soff = col < h.ld_w ? (unsigned)((m0 + mr * 32 + 4 * lh) * h.ld_w + col) * 4u : OOB;
+            const unsigned row_bytes = (unsigned)h.ld_w * 4u;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const f32x4 v = {acc[0][r], acc[1][r], acc[2][r], acc[3][r]};
+                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), rsW, soff, 0, DPK_K1_STORE_AUX);
+                soff += ((r & 3) == 3 ? 5u : 1u) * row_bytes;
+                sq += v[0] * v[0];
+                sq += v[1] * v[1];
+                sq += v[2] * v[2];
+                sq += v[3] * v[3];
+            }
+        }
+        {
+            bsum += __shfl_xor(bsum, 32, 64);
+            const float* GSb = jobs.Bi[cur.job];
+            const bool has_bias = live && GSb != nullptr && cur.tn == 0;
+            const auto rsB = make_rsrc(GSb + b * gs_stride, has_bias ? (int64_t)h.out_f * 4 : 0);
+            const bool owner = cg == 0 && lh == 0;
+            __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, bsum), rsB,
+                                                  owner ? (unsigned)(m0 + mr * 32 + l31) * 4u : OOB, 0, 0);
+            if (has_bias && owner) sq += bsum * bsum;
+        }
+        sq = wave_sum(sq);
+        if (lane == 0) red[parity * NW + wave] = sq;
+        lds_only_barrier();
+        {
+            float tot = 0.f;
+#pragma unroll
+            for (int i = 0; i < NW; ++i) tot += red[parity * NW + i];
+            const auto rsP = make_rsrc(normsq_part + b * part_stride, (int64_t)part_stride * 4);
+            // the layer's slots are [tiles_m][slot_cols]; a 256-column tile of the large plan owns two (second: 0)
+            const bool second = tid == 1 && h.slot_mul == 2 && cur.tn * 2 + 1 < h.slot_cols;
+            __builtin_amdgcn_raw_buffer_store_b32(
+                __builtin_bit_cast(unsigned, tid == 0 ? tot : 0.f), rsP,
+                (tid == 0 || second)
+                    ? (unsigned)(jobs.slot0[cur.job] + cur.tm * h.slot_cols + cur.tn * h.slot_mul + tid) * 4u
+                    : OOB,
+                0, 0);
+        }
+        parity ^= 1;
+        more = has_next;
+        cur = nxt;
+    };
+    do_item();
+    while (more) do_item();
+}
+
 // ---- persistent, split-operand variant (round 2): fp32 products on the bf16 matrix pipe --------------------------
 // On gfx950 the fp32 MFMA (v_mfma_f32_32x32x2_f32: 64 flop per cycle per SIMD) is 16x slower than the bf16 one
 // (v_mfma_f32_32x32x16_bf16: 1024), and at T = 48 the fp32 contraction alone (12.3k cycles per 128 x 256 item) is longer
@@ -1023,6 +1216,71 @@ extern "C" int dpk_lab_read_stamps(void* host, int n) {
     return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(dpk_stamps), sizeof(unsigned long long) * n);
 }
 #endif
+
+extern "C" int dpk_linear_grad_sample_multi(const dpk_k1_job* jl, int n_jobs, float* normsq_part, int64_t part_stride,
+                                            int B, int64_t gs_stride, float g_scale, void* stream) {
+    if (!jl || !normsq_part || n_jobs < 1 || n_jobs > DPK_K1_MULTI_MAX_JOBS || B < 0) return DPK_EINVAL;
+    K1MultiJobs jobs;
+    int tiles = 0, maxT = 0;
+    for (int j = 0; j < DPK_K1_MULTI_MAX_JOBS; ++j) {
+        const dpk_k1_job& q = jl[j < n_jobs ? j : 0];
+        if (j < n_jobs) {
+            if (!q.A || !q.G || !q.GSw || q.slot0 < 0 || q.T <= 0 || q.in_features <= 0 || q.out_features <= 0)
+                return DPK_EINVAL;
+            if (q.ld_w < q.in_features || q.ld_g < q.out_features || gs_stride < (int64_t)q.ld_w * q.out_features)
+                return DPK_EINVAL;
+            if (q.ld_w % 4 != 0) return DPK_EALIGN;       // 16-byte row stores
+            if (q.T > PERSIST_MAX_T) return DPK_ERANGE;   // the whole sequence of a tile is staged in LDS
+            if ((int64_t)q.out_features * q.ld_w >= (1LL << 29) ||
+                (int64_t)q.T * (q.ld_g > q.in_features ? q.ld_g : q.in_features) >= (1LL << 29))
+                return DPK_ERANGE;
+        }
+        const Plan p = pick_plan(q.in_features, q.out_features);
+        K1Shape& h = jobs.sh[j];
+        h.T = q.T; h.in_f = q.in_features; h.out_f = q.out_features; h.ld_w = q.ld_w; h.ld_g = q.ld_g;
+        h.tiles_m = (q.out_features + 127) / 128;
+        h.tiles_n = (q.in_features + 255) / 256;
+        const int slot_w = p.id == 0 ? SPLIT_CS : p.cs;
+        h.slot_cols = (q.in_features + slot_w - 1) / slot_w;
+        h.slot_mul = p.id == 0 ? 2 : 1;
+        h.tile0 = tiles;
+        if (j < n_jobs) {
+            // the wide tiles must cover the layer's slot grid exactly as dpk_linear_slots counts it
+            if (h.tiles_m != (q.out_features + p.rs - 1) / p.rs || (h.slot_mul == 1 && h.tiles_n != h.slot_cols))
+                return DPK_ERANGE;
+            if (q.slot0 + (int64_t)h.tiles_m * h.slot_cols > part_stride) return DPK_ESLOTS;
+            tiles += h.tiles_m * h.tiles_n;
+            if (q.T > maxT) maxT = q.T;
+        }
+        jobs.A[j] = q.A; jobs.G[j] = q.G; jobs.W[j] = q.GSw; jobs.Bi[j] = q.GSb; jobs.slot0[j] = q.slot0;
+    }
+    jobs.n = n_jobs;
+    jobs.tiles_total = tiles;
+    if (B == 0) return DPK_OK;
+    const int64_t items = ((int64_t)(B + 7) / 8) * 8 * tiles;
+    if (items > 0x7fffffffLL) return DPK_ERANGE;
+    int64_t want = dpk_cu_count();
+    if (want > items) want = items;
+    const dim3 grid((unsigned)((want + 7) / 8 * 8));
+    const int Tp = (maxT + 1) & ~1;
+    const size_t lds = ((size_t)Tp * (128 + 256) + 2 * 256 + 2 * 8) * sizeof(float);
+    hipStream_t s = (hipStream_t)stream;
+#define DPK_K1_MULTI_GO(NG, NA)                                                                                       \
+    do {                                                                                                              \
+        auto kfn = linear_gs_multi_kernel<NG, NA>;                                                                    \
+        if (lds > 64 * 1024) {                                                                                        \
+            hipError_t e_ = hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+            if (e_ != hipSuccess) return (int)e_;                                                                     \
+        }                                                                                                             \
+        hipLaunchKernelGGL(kfn, grid, dim3(512), lds, s, jobs, normsq_part, part_stride, B, gs_stride, g_scale);      \
+    } while (0)
+    if (maxT <= 32)
+        DPK_K1_MULTI_GO(2, 4);
+    else
+        DPK_K1_MULTI_GO(3, 6);
+#undef DPK_K1_MULTI_GO
+    return dpk_launch_status();
+}
 
 extern "C" int dpk_linear_grad_sample(const float* A, const float* G, float* GSw, float* GSb, float* normsq_part,
                                       int64_t part_stride, int slot0, int B, int T, int in_f, int out_f,

@@ -33,22 +33,28 @@ from .layers.fused_gru import FusedLinearCellGRU
 ARENA_ALIGN = 64  # floats: every parameter window starts on a 256-byte boundary
 
 
-def _row_stride(p: nn.Parameter) -> int:
+def _row_stride(p: nn.Parameter, pad: bool = True) -> int:
     """Arena row stride of a 2-D weight: rows of awkward width (>= 64 and not a multiple of 32 floats) are padded
-    to the next multiple of 32 so that K1 writes whole 128-byte lines (non-temporal) — e.g. 250 -> 256, 400 -> 416."""
+    to the next multiple of 32 so that K1 writes whole 128-byte lines (non-temporal) — e.g. 250 -> 256, 400 -> 416;
+    narrower rows are padded to a multiple of 4 floats (13 -> 16, 7 -> 8) so that every Linear layer's rows can be
+    stored 16 bytes at a time and join the small-batch multi-layer launch.  K1 writes exact zeros into the padding."""
     if p.dim() != 2:
         return p.shape[-1] if p.dim() else 1
     n = p.shape[1]
-    return (n + 31) // 32 * 32 if (n >= 64 and n % 32) else n
+    if not pad:
+        return n
+    if n >= 64:
+        return (n + 31) // 32 * 32 if n % 32 else n
+    return (n + 3) // 4 * 4
 
 
 class _ParamWindow:
     """Where one parameter's per-sample gradient lives inside an arena row (and inside summed/grad)."""
     __slots__ = ("name", "param", "offset", "numel", "ld")
 
-    def __init__(self, name, param, offset):
+    def __init__(self, name, param, offset, pad_rows=True):
         self.name, self.param, self.offset = name, param, offset
-        self.ld = _row_stride(param)
+        self.ld = _row_stride(param, pad_rows)
         self.numel = param.shape[0] * self.ld if param.dim() == 2 else param.numel()
 
     def view(self, storage: torch.Tensor, lead: Tuple[int, ...] = (), lead_stride: Tuple[int, ...] = (),
@@ -75,7 +81,9 @@ class GradSampleArena:
     summed, grad [P]        clipped sum (p.summed_grad views) and final gradient (p.grad views)
     """
 
-    def __init__(self, named_params: Iterable[Tuple[str, nn.Parameter]], device: torch.device):
+    def __init__(self, named_params: Iterable[Tuple[str, nn.Parameter]], device: torch.device, dense=()):
+        """`dense`: ids of 2-D parameters whose rows must stay unpadded (everything but Linear weights: K1 is the
+        only kernel that writes rows with a stride)."""
         self.device = device
         self.windows: Dict[int, _ParamWindow] = {}
         off = 0
@@ -84,7 +92,7 @@ class GradSampleArena:
                 continue
             if p.dtype != torch.float32:
                 raise ValueError(f"{name}: only fp32 parameters are supported (got {p.dtype})")
-            self.windows[id(p)] = _ParamWindow(name, p, off)
+            self.windows[id(p)] = _ParamWindow(name, p, off, pad_rows=id(p) not in dense)
             off += (self.windows[id(p)].numel + ARENA_ALIGN - 1) // ARENA_ALIGN * ARENA_ALIGN
         self.P = max(off, ARENA_ALIGN)
         self.n_slots = 0
@@ -228,7 +236,8 @@ class GradSampleModule(nn.Module):
         errors = self.validate(m, strict=strict)
         if errors and strict:
             raise NotImplementedError(f"Model contains layers without a per-sample-gradient kernel: {errors}")
-        self.arena = GradSampleArena(params, device)
+        linear_w = {id(sub.weight) for sub in m.modules() if _kind_of(sub) == "linear"}
+        self.arena = GradSampleArena(params, device, dense={id(p) for _, p in params if p.dim() == 2 and id(p) not in linear_w})
         # overlap_grad_sample=True issues the per-sample-gradient launches on a side stream, joined when backward
         # ends.  Measured on cfg2 (MI355X): 3.14 ms/step with overlap vs 2.97 ms without — the store-bound K1
         # launches slow the dX GEMMs / recurrence they run beside by more than the overlap hides.  Off by default.
@@ -270,6 +279,12 @@ class GradSampleModule(nn.Module):
         # fused recurrences hand their gates' stacked (activations, backprops) over directly (no per-call hooks)
         self._by_module = {id(l.module): l for l in self._layers}
         self._deferred = None  # list while _fused_sink_many collects launches
+        # Small batches (the reference's own B ~ 50): a layer's contraction is a handful of tiles per CU, and a dozen
+        # launches per backward pass each pay a ramp and a tail.  Layers whose arena rows allow 16-byte stores are
+        # then queued and contracted by ONE multi-shape launch when the backward pass ends (autograd engine callback;
+        # also flushed by check_complete()), instead of one launch per layer as its backward hook fires.
+        self.multi_launch_max_batch = 256
+        object.__setattr__(self, "_multi_pending", [])
         for sub in m.modules():
             if isinstance(sub, FusedLinearCellGRU) or "_dpk_sink" in sub.__dict__:  # fused GRU modules, DPLSTM cells
                 object.__setattr__(sub, "_dpk_sink", self._fused_sink)
@@ -517,11 +532,44 @@ class GradSampleModule(nn.Module):
             self._side.wait_stream(torch.cuda.current_stream(arena.device))
             with torch.cuda.stream(self._side):
                 self._launch(layer, m, A, G, arena, row0, part, g_scale)
+        elif B > 0 and self._multi_eligible(layer, m, A, G, arena, B):
+            if not self._multi_pending:
+                torch.autograd.Variable._execution_engine.queue_callback(self._flush_multi)
+            self._multi_pending.append((layer, m, A, G, arena, row0, part, g_scale))
         elif B > 0 and self._deferred is not None:
             self._deferred.append((layer, m, A, G, arena, row0, part, g_scale))
         elif B > 0:
             self._launch(layer, m, A, G, arena, row0, part, g_scale)
         self._publish(m, arena, row0, B, k)
+
+    def _multi_eligible(self, layer, m, A, G, arena, B) -> bool:
+        if layer.kind != "linear" or B > self.multi_launch_max_batch or self._side is not None:
+            return False
+        return _native.multi_ok(A, G, arena.window(m.weight).ld) and self._in_backward()
+
+    @staticmethod
+    def _in_backward() -> bool:
+        # queue_callback is only legal while the autograd engine runs; outside (direct _fused_sink calls in tests)
+        # launches stay immediate
+        try:
+            return torch._C._current_graph_task_id() != -1
+        except Exception:
+            return False
+
+    def _flush_multi(self):
+        """One multi-shape K1 launch for everything queued during this backward pass."""
+        pending = self._multi_pending
+        if not pending:
+            return
+        object.__setattr__(self, "_multi_pending", [])
+        by_row = {}
+        for job in pending:
+            by_row.setdefault((job[5], job[7]), []).append(job)  # (row0, g_scale): one pass = one group
+        for (row0, g_scale), jobs in by_row.items():
+            arena, part = jobs[0][4], jobs[0][6]
+            recs = [(A, G, arena.flat(m.weight, row0), arena.flat(m.bias, row0) if m.bias is not None else None,
+                     layer.slot0, arena.window(m.weight).ld) for layer, m, A, G, _, _, _, _ in jobs]
+            _native.linear_grad_sample_multi(recs, part, g_scale)
 
     def _join_side(self):
         if self._inflight:
@@ -557,6 +605,7 @@ class GradSampleModule(nn.Module):
     # ---- used by the optimizer ------------------------------------------------------------------------
     def check_complete(self):
         self._join_side()  # no-op unless per-sample gradients were produced outside an autograd backward pass
+        self._flush_multi()
         n = len(self.arena.pass_B)
         for layer in self._layers:
             if layer.passes_written != n:

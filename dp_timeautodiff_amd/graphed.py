@@ -112,7 +112,10 @@ class GraphedDPStep:
         return self
 
     def _collective_capturable(self) -> bool:
+        import os
         import torch.distributed as dist
+        if os.environ.get("DPK_GRAPH_EXCHANGE", "1") == "0":  # operator's switch: keep the exchange out of the graph
+            return False
         try:
             return dist.get_backend(self.optimizer.process_group) == "nccl"
         except Exception:

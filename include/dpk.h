@@ -90,6 +90,28 @@ int dpk_linear_grad_sample_group(const float* const* A, const float* const* G, f
                                  int64_t gs_stride, int ld_w, int ld_g, float g_scale, void* stream);
 
 /*
+ * K1, many layers of DIFFERENT shapes in one launch — for the reference's own batch size (B ~ 50, dp_job.sh), where a
+ * layer's launch is a handful of tiles per CU and the twelve launches of one backward pass (timeautoencoder.py:749) each
+ * pay a ramp and a tail.  `jobs` is a HOST array of n_jobs <= DPK_K1_MULTI_MAX_JOBS descriptors (device pointers inside);
+ * every job is what one dpk_linear_grad_sample call would take and writes the same dpk_linear_slots(in,out) partials at
+ * its slot0.  Requirements per job: T <= 48, ld_w % 4 == 0 (DPK_EALIGN otherwise: such layers keep their own launch).
+ * All jobs share B, gs_stride (one arena), part_stride and g_scale.  Results equal per-layer calls on the fp32 matrix
+ * pipe bit for bit for layers of the large plan (in > 128, out > 32); for thinner layers the weights are bit-identical
+ * and the bias differs in summation order only.
+ */
+#define DPK_K1_MULTI_MAX_JOBS 32
+typedef struct {
+    const float* A;   /* [B,T,in] */
+    const float* G;   /* [B,T,out], row stride ld_g */
+    float* GSw;       /* window of the weight in arena row 0 */
+    float* GSb;       /* window of the bias, or NULL */
+    int slot0, T, in_features, out_features, ld_w, ld_g;
+} dpk_k1_job;
+int dpk_linear_grad_sample_multi(const dpk_k1_job* jobs, int n_jobs, float* normsq_part, int64_t part_stride,
+                                 int B, int64_t gs_stride, float g_scale, void* stream);
+
+
+/*
  * K3 — per-sample gradient of nn.Embedding.  Replaces Opacus' Embedding sampler
  *     zeros(B,V,E).scatter_add_(1, index, backprops)     (Embedding_data, timeautoencoder.py:128-133,160-164)
  * idx [B,T] int64 (values in [0,V)), G [B,T,E]; GS[b,v,:] = sum_{t: idx[b,t]=v} g_scale*G[b,t,:], summed in

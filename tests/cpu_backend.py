@@ -114,7 +114,16 @@ def philox_normal(out, seed, offset, std):
     out.copy_(torch.from_numpy(O.philox_normal(out.numel(), seed, offset, std)))
 
 
-PATCHED = ["linear_slots", "normsq_slots", "linear_grad_sample", "embedding_grad_sample", "layernorm_grad_sample",
+def multi_ok(A, G, ld_w):
+    return A.dim() == 3 and G.dim() == 3 and A.shape[1] <= 48 and ld_w % 4 == 0
+
+
+def linear_grad_sample_multi(jobs, part, g_scale):
+    for A, G, gs_w, gs_b, slot0, ld_w in jobs:  # same host protocol, one layer at a time
+        linear_grad_sample(A, G, gs_w, gs_b, part, slot0, g_scale, ld_w=ld_w)
+
+
+PATCHED = ["linear_slots", "normsq_slots", "linear_grad_sample", "linear_grad_sample_multi", "multi_ok", "embedding_grad_sample", "layernorm_grad_sample",
            "clip_factors", "clip_reduce_workspace", "clip_reduce", "noise_scale", "clip_reduce_noise",
            "philox_normal"]
 

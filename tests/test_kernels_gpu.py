@@ -508,3 +508,84 @@ def test_linear_grad_sample_arithmetic_modes_are_fp32_accurate(nat, monkeypatch,
         assert float((part.double().sum(1) / sq - 1).abs().max()) < 1e-6, mode
     assert errs["split6"] <= 2.0 * errs["split9"] + 2e-8, errs
     assert errs["split8"] <= 1.25 * errs["split9"] + 1e-8, errs
+
+
+MULTI_LAYERS = [
+    # (T, in, out, bias) — the cfg1 VAE's layers with 16-byte-storable rows, plus odd ones
+    (24, 400, 200, True), (24, 400, 200, True), (24, 208, 208, True), (24, 208, 128, True), (24, 200, 200, True),
+    (24, 128, 13, True), (24, 200, 7, True), (24, 200, 13, False), (1, 130, 33, True), (31, 300, 260, True),
+    (48, 512, 97, True), (24, 32, 128, True), (7, 64, 300, False), (24, 400, 200, True), (24, 400, 200, True),
+    (24, 400, 200, True), (24, 400, 200, True), (12, 160, 40, True),
+]
+
+
+@pytest.mark.parametrize("B,max_jobs", [(50, None), (7, None), (130, None), (50, 5)])
+def test_linear_grad_sample_multi_equals_single_launches(nat, monkeypatch, B, max_jobs):
+    """dpk_linear_grad_sample_multi (layers of different shapes in one launch: the small-batch path) against one
+    dpk_linear_grad_sample call per layer on the fp32 matrix pipe: weights bit for bit for every layer; bias and
+    squared-norm partials bit for bit for layers of the large plan (thinner layers sum the bias in another order)."""
+    monkeypatch.setenv("DPK_K1_MFMA", "f32")
+    if max_jobs:  # the host wrapper cuts longer job lists into several launches
+        monkeypatch.setattr(nat, "K1_MULTI_MAX_JOBS", max_jobs)
+    g = torch.Generator().manual_seed(B)
+    lds = [(i + 31) // 32 * 32 if (i >= 64 and i % 32) else i for _, i, _, _ in MULTI_LAYERS]
+    wins = [(ld * o + 63) // 64 * 64 for ld, (_, _, o, _) in zip(lds, MULTI_LAYERS)]
+    bw = [(o + 63) // 64 * 64 for _, _, o, _ in MULTI_LAYERS]
+    offs, off = [], 0
+    for w, b in zip(wins, bw):
+        offs.append(off)
+        off += w + b
+    row = off
+    slots = [nat.linear_slots(i, o) for _, i, o, _ in MULTI_LAYERS]
+    s0 = [sum(slots[:k]) for k in range(len(slots))]
+    As = [torch.randn(B, T, i, generator=g).cuda() for T, i, _, _ in MULTI_LAYERS]
+    Gs = [(torch.randn(B, T, o, generator=g) * 0.01).cuda() for T, _, o, _ in MULTI_LAYERS]
+
+    def views(base, k):
+        _, _, o, bias = MULTI_LAYERS[k]
+        return (nat.FlatView(base, offs[k], lds[k] * o), nat.FlatView(base, offs[k] + wins[k], o) if bias else None)
+
+    one = torch.full((B, row), 3.0, device="cuda")
+    p_one = torch.full((B, sum(slots) + 2), -1.0, device="cuda")
+    for k in range(len(MULTI_LAYERS)):
+        vw, vb = views(one, k)
+        nat.linear_grad_sample(As[k], Gs[k], vw, vb, p_one, s0[k], float(B), ld_w=lds[k])
+    many = torch.full((B, row), 3.0, device="cuda")
+    p_many = torch.full((B, sum(slots) + 2), -1.0, device="cuda")
+    assert all(nat.multi_ok(As[k], Gs[k], lds[k]) for k in range(len(MULTI_LAYERS)))
+    nat.linear_grad_sample_multi([(As[k], Gs[k], *views(many, k), s0[k], lds[k]) for k in range(len(MULTI_LAYERS))],
+                                 p_many, float(B))
+    torch.cuda.synchronize()
+    for k, (T, i, o, bias) in enumerate(MULTI_LAYERS):
+        w1 = one[:, offs[k]:offs[k] + lds[k] * o]
+        w2 = many[:, offs[k]:offs[k] + lds[k] * o]
+        assert torch.equal(w1, w2), (k, "weight")
+        large = i > 128 and o > 32
+        if bias:
+            b1 = one[:, offs[k] + wins[k]:offs[k] + wins[k] + o]
+            b2 = many[:, offs[k] + wins[k]:offs[k] + wins[k] + o]
+            assert torch.equal(b1, b2) if large else rel_err(b2.cpu().numpy(), b1.cpu().numpy()) < 1e-6, (k, "bias")
+        q1 = p_one[:, s0[k]:s0[k] + slots[k]]
+        q2 = p_many[:, s0[k]:s0[k] + slots[k]]
+        if large:
+            assert torch.equal(q1, q2), (k, "normsq")
+        else:
+            assert rel_err(q2.double().sum(1).cpu().numpy(), q1.double().sum(1).cpu().numpy()) < 1e-6, (k, "normsq")
+    assert (p_many[:, sum(slots):] == -1).all()
+    # nothing outside the windows was touched
+    mask = torch.ones(row, dtype=torch.bool)
+    for k, (T, i, o, bias) in enumerate(MULTI_LAYERS):
+        mask[offs[k]:offs[k] + lds[k] * o] = False
+        if bias:
+            mask[offs[k] + wins[k]:offs[k] + wins[k] + o] = False
+    assert (many[:, mask.cuda()] == 3.0).all()
+
+
+def test_linear_grad_sample_multi_refuses_what_it_cannot_store(nat):
+    A = torch.randn(4, 24, 13, device="cuda")
+    G = torch.randn(4, 24, 200, device="cuda")
+    base = torch.zeros(4, 13 * 200 + 256, device="cuda")
+    part = torch.zeros(4, 8, device="cuda")
+    assert not nat.multi_ok(A, G, 13)
+    with pytest.raises(nat.DpkError):
+        nat.linear_grad_sample_multi([(A, G, nat.FlatView(base, 0, 13 * 200), None, 0, 13)], part, 4.0)
