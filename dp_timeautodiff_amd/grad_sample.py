@@ -21,6 +21,7 @@ MI355X-first differences (observable state after backward is the same: `p.grad_s
 """
 from __future__ import annotations
 
+import os
 from typing import Dict, Iterable, List, Optional, Tuple
 
 import torch
@@ -283,7 +284,7 @@ class GradSampleModule(nn.Module):
         # launches per backward pass each pay a ramp and a tail.  Layers whose arena rows allow 16-byte stores are
         # then queued and contracted by ONE multi-shape launch when the backward pass ends (autograd engine callback;
         # also flushed by check_complete()), instead of one launch per layer as its backward hook fires.
-        self.multi_launch_max_batch = 256
+        self.multi_launch_max_batch = int(os.environ.get("DPK_MULTI_LAUNCH_MAX_BATCH", "256"))
         object.__setattr__(self, "_multi_pending", [])
         for sub in m.modules():
             if isinstance(sub, FusedLinearCellGRU) or "_dpk_sink" in sub.__dict__:  # fused GRU modules, DPLSTM cells
