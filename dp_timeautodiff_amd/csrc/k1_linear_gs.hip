@@ -1028,10 +1028,6 @@ __global__ void __launch_bounds__(256, 2) linear_gs_split_kernel(
 #endif
 }
 
-#ifdef DPK_K1_PIPE  // lab builds only: the software-pipelined variant (measured, not adopted: DESIGN.md 8.5)
-#include "../../tools/lab/k1_pipe.inc"
-#endif
-
 inline int dpk_cu_count() {
     static int cached[64] = {0};
     int dev = 0;
