@@ -906,6 +906,10 @@ __global__ void __launch_bounds__(256, 2) linear_gs_split_kernel(
 #ifdef DPK_K1_STAMPS
         st_last = __builtin_amdgcn_s_memtime();
         ++st_items;
+#if DPK_K1_STAMPS == 2
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        STAMP(7);
+#endif
 #endif
         // ARES, step c = -1: the group's A slice.  Every wave has passed the previous tile's closing barrier, so nobody
         // reads A any more; the first G step's barrier publishes it.  Same stage / prefetch code, nothing else.

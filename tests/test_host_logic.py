@@ -147,3 +147,12 @@ def test_noise_and_sampler_streams_are_domain_separated():
     # per-rank sampler keys differ, and none of them is the noise key
     ks = {rng.stream_key((9 + rng.RANK_STRIDE * r) & (2**64 - 1), "sampler") for r in range(8)}
     assert len(ks) == 8 and rng.stream_key(9, "noise") not in ks
+
+
+def test_secure_mode_is_refused_not_degraded():
+    """Opacus fails hard when it cannot provide a cryptographically secure generator; so does this build
+    (the Philox noise kernels and the device sampler are not CSPRNG-backed)."""
+    from dp_timeautodiff_amd.privacy_engine import PrivacyEngine
+    with pytest.raises(NotImplementedError):
+        PrivacyEngine(secure_mode=True)
+    PrivacyEngine(secure_mode=False)
