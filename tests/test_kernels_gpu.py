@@ -589,3 +589,17 @@ def test_linear_grad_sample_multi_refuses_what_it_cannot_store(nat):
     assert not nat.multi_ok(A, G, 13)
     with pytest.raises(nat.DpkError):
         nat.linear_grad_sample_multi([(A, G, nat.FlatView(base, 0, 13 * 200), None, 0, 13)], part, 4.0)
+
+
+def test_linear_grad_sample_random_shapes(nat):
+    """Seeded sweep over shapes no hand-written list would contain: every kernel choice (thin plans, wide-unit, split
+    with and without the resident A slice, chunked long sequences), ragged tiles, padded and unpadded rows, groups."""
+    rs = np.random.RandomState(20261111)
+    for case in range(48):
+        T = int(rs.choice([1, 2, 3, 7, 16, 17, 24, 31, 32, 33, 40, 47, 48, 49, 63, 64, 65, 90, 130]))
+        in_f = int(rs.choice([1, 5, 13, 31, 64, 100, 128, 129, 200, 250, 257, 300, 512, 640]))
+        out_f = int(rs.choice([1, 7, 32, 33, 64, 100, 127, 128, 129, 200, 260]))
+        B = int(rs.randint(1, 20))
+        nj = int(rs.choice([1, 1, 1, 2, 3]))
+        bias = bool(rs.randint(0, 2))
+        _arena_case(nat, B, T, in_f, out_f, nj, bias, seed=1000 + case)
