@@ -286,6 +286,10 @@ class GradSampleModule(nn.Module):
         # also flushed by check_complete()), instead of one launch per layer as its backward hook fires.
         self.multi_launch_max_batch = int(os.environ.get("DPK_MULTI_LAUNCH_MAX_BATCH", "256"))
         object.__setattr__(self, "_multi_pending", [])
+        # autograd graph-task id of the backward pass whose end-of-pass callback is already queued (one per pass: a
+        # pass that raises never runs its callbacks, so "the list is non-empty" cannot stand in for "a flush is queued")
+        object.__setattr__(self, "_multi_task", None)
+        object.__setattr__(self, "_side_task", None)
         for sub in m.modules():
             if isinstance(sub, FusedLinearCellGRU) or "_dpk_sink" in sub.__dict__:  # fused GRU modules, DPLSTM cells
                 object.__setattr__(sub, "_dpk_sink", self._fused_sink)
@@ -327,9 +331,17 @@ class GradSampleModule(nn.Module):
         super().zero_grad(set_to_none)
 
     def _reset_step_state(self):
+        """Forget every un-stepped backward pass: also what a pass that RAISED left behind (queued multi-shape jobs and
+        half-collected (A, G) pairs would otherwise join the next pass's launch and write the same arena windows)."""
         self.arena.reset_pass()
         for layer in self._layers:
             layer.passes_written = 0
+            layer.pairs = []
+        self._multi_pending.clear()
+        object.__setattr__(self, "_multi_task", None)
+        if self._inflight:
+            self._join_side()
+        object.__setattr__(self, "_side_task", None)
 
     def del_grad_sample(self):
         for p in self.parameters():
@@ -526,16 +538,23 @@ class GradSampleModule(nn.Module):
         g_scale = float(B) if self.loss_reduction == "mean" else 1.0
         part = arena.part[row0:] if row0 else arena.part
         if B > 0 and self._side is not None:
-            if not self._inflight:
+            task = self._graph_task()
+            if task != -1 and task != self._side_task:
                 # first launch of this backward pass: join when the autograd engine finishes the pass
                 torch.autograd.Variable._execution_engine.queue_callback(self._join_side)
+                object.__setattr__(self, "_side_task", task)
             self._inflight.append((A, G))
             self._side.wait_stream(torch.cuda.current_stream(arena.device))
             with torch.cuda.stream(self._side):
                 self._launch(layer, m, A, G, arena, row0, part, g_scale)
         elif B > 0 and self._multi_eligible(layer, m, A, G, arena, B):
-            if not self._multi_pending:
+            task = self._graph_task()
+            if task != self._multi_task:
+                # first eligible layer of THIS backward pass.  Anything still queued belongs to a pass that raised
+                # before its callback ran (a completed pass flushes): its rows are about to be rewritten, drop it.
+                self._multi_pending.clear()
                 torch.autograd.Variable._execution_engine.queue_callback(self._flush_multi)
+                object.__setattr__(self, "_multi_task", task)
             self._multi_pending.append((layer, m, A, G, arena, row0, part, g_scale))
         elif B > 0 and self._deferred is not None:
             self._deferred.append((layer, m, A, G, arena, row0, part, g_scale))
@@ -549,17 +568,22 @@ class GradSampleModule(nn.Module):
         return _native.multi_ok(A, G, arena.window(m.weight).ld) and self._in_backward()
 
     @staticmethod
-    def _in_backward() -> bool:
+    def _graph_task() -> int:
+        try:
+            return torch._C._current_graph_task_id()
+        except Exception:
+            return -1
+
+    @classmethod
+    def _in_backward(cls) -> bool:
         # queue_callback is only legal while the autograd engine runs; outside (direct _fused_sink calls in tests)
         # launches stay immediate
-        try:
-            return torch._C._current_graph_task_id() != -1
-        except Exception:
-            return False
+        return cls._graph_task() != -1
 
     def _flush_multi(self):
         """One multi-shape K1 launch for everything queued during this backward pass."""
         pending = self._multi_pending
+        object.__setattr__(self, "_multi_task", None)
         if not pending:
             return
         object.__setattr__(self, "_multi_pending", [])
@@ -573,6 +597,7 @@ class GradSampleModule(nn.Module):
             _native.linear_grad_sample_multi(recs, part, g_scale)
 
     def _join_side(self):
+        object.__setattr__(self, "_side_task", None)
         if self._inflight:
             torch.cuda.current_stream(self.arena.device).wait_stream(self._side)
             self._inflight.clear()

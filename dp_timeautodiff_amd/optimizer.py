@@ -307,8 +307,7 @@ class DPOptimizer(Optimizer):
                 arena.summed_valid = False
             arena.reset_pass()
         if self._gsm is not None:
-            for layer in self._gsm._layers:
-                layer.passes_written = 0
+            self._gsm._reset_step_state()  # also drops what a backward pass that raised left queued
         if not set_to_none and arena is not None and arena.grad is not None and self._grads_live_in(arena):
             arena.grad.zero_()  # every p.grad is a view of this one vector: one fill instead of one per parameter
         else:

@@ -265,6 +265,61 @@ def test_poisson_forbids_grad_accumulation_and_missing_layer_raises(dev):
         opt.step()
 
 
+def test_backward_that_raises_leaves_nothing_behind(dev):
+    """at B <= 256 the Linear contractions are queued for ONE launch at the end of backward.  A
+    backward pass that raises never runs its end-of-pass callback; after zero_grad the next pass must be a clean one
+    (no stale job sharing its rows), and must queue its own flush."""
+    from dp_timeautodiff_amd.grad_sample import GradSampleModule
+    from dp_timeautodiff_amd.optimizer import DPOptimizer
+
+    class Boom(RuntimeError):
+        pass
+
+    def build():
+        torch.manual_seed(3)
+        net = torch.nn.Sequential(torch.nn.Linear(8, 12), torch.nn.Tanh(), torch.nn.Linear(12, 4)).to(dev)
+        gsm = GradSampleModule(net)
+        opt = DPOptimizer(torch.optim.SGD(net.parameters(), lr=0.1), noise_multiplier=0.0, max_grad_norm=0.3,
+                          expected_batch_size=6)
+        opt.attach_grad_sample_module(gsm)
+        return net, gsm, opt
+
+    g = torch.Generator().manual_seed(5)
+    x_bad = torch.randn(6, 5, 8, generator=g).to(dev)
+    x = torch.randn(6, 5, 8, generator=g).to(dev)
+
+    net1, gsm1, opt1 = build()
+    opt1.zero_grad()
+    gsm1(x).square().mean().backward()
+    opt1.step()
+
+    net2, gsm2, opt2 = build()
+    opt2.zero_grad()
+    h = net2[0](x_bad)
+
+    def explode(_):
+        raise Boom()
+
+    h.register_hook(explode)  # fires after the last layer's backward hook has queued its contraction
+    with pytest.raises(Boom):
+        gsm2._module[2](gsm2._module[1](h)).square().mean().backward()
+    opt2.zero_grad()
+    assert not gsm2._multi_pending and all(not l.pairs for l in gsm2._layers)
+    # the first layer's stashed input never met its backprop; like Opacus' activation stacks it is not zero_grad's to
+    # drop (a forward may legally precede zero_grad), and leaving it makes the next step fail loudly in check_complete
+    for l in gsm2._layers:
+        l.acts.clear()
+        l.counter = 0
+    for p in net2.parameters():
+        p._forward_counter = 0
+    gsm2(x).square().mean().backward()
+    assert not gsm2._multi_pending  # this pass queued (and ran) its own flush
+    opt2.step()
+    for p1, p2 in zip(net1.parameters(), net2.parameters()):
+        assert torch.equal(p1.grad_sample, p2.grad_sample)
+        assert torch.equal(p1.grad, p2.grad)
+
+
 def test_empty_poisson_batch_gives_pure_noise(dev):
     from dp_timeautodiff_amd.grad_sample import GradSampleModule
     from dp_timeautodiff_amd.optimizer import DPOptimizer
