@@ -25,6 +25,7 @@ EXPORTS = {
     "dpk_embedding_slots": (c_int, [c_int, c_int]),
     "dpk_layernorm_slots": (c_int, [c_int]),
     "dpk_normsq_slots": (c_int, [c_int64]),
+    "dpk_linear_configure": (c_int, [c_int, c_int]),
     "dpk_linear_grad_sample": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int,
                                        c_int, c_int, c_int, c_int, c_int64, c_int, c_float, c_void_p]),
     "dpk_linear_grad_sample_group": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_int64,
@@ -128,6 +129,17 @@ class FlatView:
 
 
 # ---- thin, shape-checked wrappers ---------------------------------------------------------------
+_K1_ARITHMETIC = {None: -1, "default": -1, "f32": 0, "split6": 6, "split8": 8, "split9": 9}
+
+
+def linear_configure(arithmetic="unchanged", role_split="unchanged"):
+    """Process-wide choice among K1's large-layer kernels (include/dpk.h: dpk_linear_configure).
+    arithmetic: None/"default" | "f32" | "split6" | "split8" | "split9"; role_split: None (default) | True | False."""
+    a = -2 if arithmetic == "unchanged" else _K1_ARITHMETIC[arithmetic]
+    r = -2 if role_split == "unchanged" else (-1 if role_split is None else int(bool(role_split)))
+    _check(load().dpk_linear_configure(a, r), "dpk_linear_configure")
+
+
 
 
 def linear_slots(in_f: int, out_f: int) -> int:

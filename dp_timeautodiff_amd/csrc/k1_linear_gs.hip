@@ -686,6 +686,39 @@ __device__ __forceinline__ unsigned pack_bf16_rn(float lo, float hi) {
 __device__ __forceinline__ float rest_lo(float lo, unsigned pk) { return lo - __builtin_bit_cast(float, pk << 16); }
 __device__ __forceinline__ float rest_hi(float hi, unsigned pk) { return hi - __builtin_bit_cast(float, pk & 0xffff0000u); }
 
+// ---- hand-counted operand loads --------------------------------------------------------------------------------------
+// gfx950 has ONE in-order counter (vmcnt) for a wave's vector-memory loads and stores.  A wait for operands that were
+// requested two steps ago must therefore name exactly how many younger operations may stay in flight; the compiler's
+// own wait is the minimum over every path it can see through the loop (in this kernel: vmcnt(0) / vmcnt(8), i.e. "my
+// last tile's rows have reached memory"), which serialised each wave's stores with its next chunk.  The operand loads
+// are therefore issued from inline assembly, which the compiler's counter does not track, and waited for with an
+// explicit count.  Contract kept by the code below (checked in the ISA by tools/check_k1_vmcnt.py):
+//   * every step issues SPLIT_VM_PER_STEP vector-memory instructions: 8 operand loads, then 18 stores (real rows, or
+//     out-of-range 4-byte stand-ins on steps that store nothing; range-checked away by the hardware);
+//   * the registers a load writes are not read before split_wait_loads() has named them as its in/out operands.
+constexpr int SPLIT_VM_LOADS = 8, SPLIT_VM_STORES = 18, SPLIT_VM_PER_STEP = SPLIT_VM_LOADS + SPLIT_VM_STORES;
+// operands of step i were requested in step i-2, ahead of that step's stores: younger = 18 + 26
+constexpr int SPLIT_VM_YOUNGER = SPLIT_VM_STORES + SPLIT_VM_PER_STEP;
+static_assert(SPLIT_VM_YOUNGER < 64, "vmcnt is a 6-bit counter");
+
+__device__ __forceinline__ u32x4 rsrc_words(const void* base, int64_t bytes) {
+    const unsigned long long a = reinterpret_cast<unsigned long long>(base);
+    return u32x4{(unsigned)a, (unsigned)(a >> 32) & 0xffffu, (unsigned)bytes, 0x00020000u};
+}
+__device__ __forceinline__ f32x4 asm_buffer_load_b128(const u32x4 rs, unsigned off) {
+    f32x4 v;
+    asm volatile("buffer_load_dwordx4 %0, %1, %2, 0 offen ; DPK_OPLOAD" : "=v"(v) : "v"(off), "s"(rs) : "memory");
+    return v;
+}
+template <int N>
+__device__ __forceinline__ void split_wait_loads(f32x4 (&r)[2][4]) {
+    asm volatile("s_waitcnt vmcnt(%8) ; DPK_OPWAIT %0 %1 %2 %3 %4 %5 %6 %7"
+                 : "+v"(r[0][0]), "+v"(r[0][1]), "+v"(r[0][2]), "+v"(r[0][3]), "+v"(r[1][0]), "+v"(r[1][1]),
+                   "+v"(r[1][2]), "+v"(r[1][3])
+                 : "n"(N)
+                 : "memory");
+}
+
 #ifndef DPK_K1_ABL
 #define DPK_K1_ABL 0  // lab ablations (results wrong): 1 = drop the stores, 2 = skip the MFMAs, 4 = skip the staging
 #endif
@@ -817,7 +850,7 @@ __global__ void __launch_bounds__(256, 2) linear_gs_split_kernel(
             const float* base = isG ? jobs.G[job] + b * T * ld_g : jobs.A[job] + b * T * in_f;
             // rows at or past T lie beyond the descriptor: no per-row test
             const int64_t bytes = !valid ? 0 : isG ? ((int64_t)(T - 1) * ld_g + out_f) * 4 : (int64_t)T * in_f * 4;
-            const auto rs = make_rsrc(base, bytes);
+            const u32x4 rs = rsrc_words(base, bytes);
             const int idx = wbase + lane - (isG ? 0 : Gpad);
             const int tq = idx >> 5;
             const int col = (isG ? x.tm * RS : x.tn * CS) + (idx & 31) * 4;
@@ -827,7 +860,7 @@ __global__ void __launch_bounds__(256, 2) linear_gs_split_kernel(
             const unsigned rowb = (unsigned)ld * 4u;
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
-                r[k][i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, off, 0, 0));
+                r[k][i] = asm_buffer_load_b128(rs, off);
                 off += rowb;  // an out-of-range offset stays out of range
             }
         }
@@ -893,8 +926,18 @@ __global__ void __launch_bounds__(256, 2) linear_gs_split_kernel(
 #endif
     Cur n1 = next(cur);
     Cur n2 = next(n1);
+    auto standin_stores = [&](int n) {  // out-of-range: dropped by the range check, counted by vmcnt
+        const auto rsN = make_rsrc(normsq_part, 0);
+        for (int q = 0; q < n; ++q) {
+            __builtin_amdgcn_raw_buffer_store_b32(0u, rsN, OOB, 0, 0);
+            asm volatile("" ::: "memory");
+        }
+    };
+    // the first two steps find the same number of younger operations behind their operands as every later one
     prefetch(rq[0], cur);
+    standin_stores(SPLIT_VM_STORES);
     prefetch(rq[1], n1);
+    standin_stores(SPLIT_VM_STORES);
     int parity = 0;
     f32x16 acc[4];
     float bsum = 0.f;
@@ -921,6 +964,10 @@ __global__ void __launch_bounds__(256, 2) linear_gs_split_kernel(
                 for (int q = 0; q < 16; ++q) acc[j][q] = 0.f;
             bsum = 0.f;
         }
+        split_wait_loads<SPLIT_VM_YOUNGER>(r);
+#if defined(DPK_K1_STAMPS) && DPK_K1_STAMPS == 1
+        STAMP(7);
+#endif
         if (!(DPK_K1_ABL & 4)) stage(r, cur);
         STAMP(0);
         if (!astep) lds_only_barrier();
@@ -966,8 +1013,7 @@ __global__ void __launch_bounds__(256, 2) linear_gs_split_kernel(
             }
         }
         STAMP(3);
-        if (astep) {
-        } else if (!MULTI || cur.c == nch - 1) {
+        if (!astep && (!MULTI || cur.c == nch - 1)) {
             // stores: accumulator row slot m = (q&3) + 8*(q>>2) + 4*lh of MFMA block mr is feature m0 + 4*m + mr; rows
             // >= out_f fall outside the descriptor, columns >= ld_w get the out-of-range offset
             float sq = 0.f;
@@ -1010,7 +1056,11 @@ __global__ void __launch_bounds__(256, 2) linear_gs_split_kernel(
             }
             parity ^= 1;
         } else {
-            lds_only_barrier();  // all waves done with this chunk's images
+            // a step that stores nothing (an A step, a chunk that is not the tile's last) issues as many out-of-range
+            // 4-byte stores as a storing step has stores: the hand-counted wait above needs one count for all paths
+            standin_stores(SPLIT_VM_STORES - 1);
+            if (!astep) lds_only_barrier();  // all waves done with this chunk's images
+            standin_stores(1);
         }
         STAMP(5);
         cur = n1;
@@ -1032,6 +1082,300 @@ __global__ void __launch_bounds__(256, 2) linear_gs_split_kernel(
 #endif
 }
 
+// ---- role-split variant (round 3): loaders and contractors are different waves -------------------------------------
+// What bounded linear_gs_split_kernel at 32 < T <= 48 (ablations on the MI355X, 250 -> 1000, B = 4096: everything 1146 us;
+// MFMAs and stores with NO wait on an operand load 791; the same with the waits 1046): a CU's vector-memory pipe is one
+// in-order queue.  A tile's 64 KB of rows take ~5k cycles to leave at the CU's share of the HBM rate, whoever issues a
+// vector-memory instruction meanwhile waits for room in the queue, and an operand load sits behind whatever rows were
+// queued before it.  A wave that loads, splits, contracts AND stores is therefore a serial chain "rows out -> my loads
+// come back -> split -> contract", and two such chains per CU left the queue empty about a third of the time.
+//
+// Here ONE workgroup of 12 waves owns the CU and the roles are split (3 waves per SIMD, <= 168 registers):
+//   * waves 0-3 and 4-7 are two CONTRACTOR groups; a group owns a 128 x 128 tile (wave = 32 x 128 unit, as above) and
+//     alternates phase by phase between contracting its next tile (LDS reads + bf16-pipe MFMAs, nothing else) and storing
+//     the tile it has just contracted (16 row stores per wave + bias + squared norm).  The groups are one phase apart: in
+//     every phase exactly one of them is pushing rows into the memory queue, so the queue always holds a tile's rows;
+//   * waves 8-11 are LOADERS: they fetch the operands two phases ahead (they never store a row, so nothing of theirs
+//     waits behind rows of their own), split them into the three bf16 images and stage them:
+//     during phase n the G slice of tile n+1 goes into the image buffer of the group that is storing (its contraction
+//     of tile n-1 is over).  The A slice of a (sample, column tile) group of row tiles stays resident, as in MODE 2;
+//     it is restaged in one extra phase per group of tiles (nobody contracts then; the storing group keeps the queue fed).
+//   * one LDS-only barrier of all 12 waves per phase.
+// Tile n of a workgroup is row tile n % tiles_m of its (n / tiles_m)-th (job, sample, column tile) group; groups are
+// dealt round-robin to the workgroups of the XCD that owns the sample (b mod 8).  Arithmetic per output element, k
+// order and bias pairing are those of linear_gs_split_kernel: results are bit-identical to it.
+constexpr int WS_THREADS = 768;
+constexpr int WS_PROD0 = 512;            // first loader thread
+constexpr int WS_ROWCH = 7;              // 16-byte chunks per image row: 48 steps of bf16 = 6, +1 (odd: conflict-free)
+constexpr int WS_ROWB = WS_ROWCH * 16;   // 112 bytes
+constexpr int WS_PS = 128 * WS_ROWB;     // piece stride
+constexpr int WS_IMG = 3 * WS_PS;        // one operand slice as three bf16 images: 43,008 bytes
+constexpr int WS_KC = 3;                 // MFMA k-steps of 16: 32 < T <= 48
+constexpr int WS_NQ = 4 * WS_KC;         // 4-step groups of a 48-step (k-step padded) sequence
+constexpr int WS_LDS = 3 * WS_IMG + 2 * WS_NQ * 128 * 4 + 2 * 4 * 4;  // A, G[2], bias partials[2], red[2][4]
+template <int TERMS>
+__global__ void __launch_bounds__(WS_THREADS) linear_gs_ws_kernel(
+    const K1Jobs jobs, float* __restrict__ normsq_part, int64_t part_stride, int B, int T, int in_f, int out_f,
+    int64_t gs_stride, int ld_w, int ld_g, float g_scale, int tiles_m, int tiles_n) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_b[];
+    unsigned char* sA = smem_b;                           // [3][128][ROWB]   resident A slice of the current tile group
+    unsigned char* sG = smem_b + WS_IMG;                  // [2][3][128][ROWB] G slice of tile n in buffer n & 1
+    float* sBias = reinterpret_cast<float*>(smem_b + 3 * WS_IMG);   // [2][WS_NQ][128]
+    float* red = sBias + 2 * WS_NQ * 128;                           // [2][4]
+
+    const int xcd = blockIdx.x & 7;
+    const unsigned rank = blockIdx.x >> 3;
+    const unsigned nbx = gridDim.x >> 3;
+    const unsigned nsx = (unsigned)((B - xcd + 7) / 8);
+    const unsigned per_job = nsx * (unsigned)tiles_n;
+    const unsigned total_sg = per_job * (unsigned)jobs.n;   // (job, sample, column tile) groups of this XCD
+    if (rank >= total_sg) return;                            // uniform
+    const int N = (int)((total_sg - rank + nbx - 1) / nbx) * tiles_m;   // tiles of this workgroup
+
+    struct Tile {
+        int job, s, tm, tn;
+        bool ok;
+    };
+    auto locate = [&](int n) {
+        Tile x = {0, 0, 0, 0, false};
+        if (n < 0 || n >= N) return x;
+        const unsigned u = (unsigned)n / (unsigned)tiles_m;
+        const unsigned U = rank + u * nbx;
+        x.ok = true;
+        x.tm = n - (int)u * tiles_m;
+        x.job = (int)(U / per_job);
+        const unsigned r = U - (unsigned)x.job * per_job;
+        x.s = (int)(r / (unsigned)tiles_n);
+        x.tn = (int)(r - (unsigned)x.s * (unsigned)tiles_n);
+        return x;
+    };
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int l31 = lane & 31;
+    const int lh = lane >> 5;
+
+    if (wave < 8) {
+        // ================================ contractors ================================
+        const int g = wave >> 2, mr = wave & 3;
+        unsigned char* myG = sG + g * WS_IMG;
+        const float* myBias = sBias + g * WS_NQ * 128;
+        f32x16 acc[4];
+        float bsum = 0.f;
+
+        auto contract = [&](const Tile&) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+                for (int q = 0; q < 16; ++q) acc[j][q] = 0.f;
+            // Column block by column block (the 6 products of one accumulator back to back, smallest first: the order of
+            // every accumulator's own chain is that of linear_gs_split_kernel), so that only one block's A operands and
+            // the next block's are live: 48 operand registers instead of 60 + 60, which is what fits 168.
+            const unsigned char* pg = myG + (mr * 32 + l31) * WS_ROWB + lh * 16;
+            const unsigned char* pa = sA + l31 * WS_ROWB + lh * 16;
+            bf16x8 gv[2][3], av[2][3];
+            auto load_g = [&](bf16x8 (&d)[3], int ks) {
+#pragma unroll
+                for (int p = 0; p < 3; ++p) d[p] = *reinterpret_cast<const bf16x8*>(pg + p * WS_PS + ks * 32);
+            };
+            auto load_a = [&](bf16x8 (&d)[3], int ks, int j) {
+#pragma unroll
+                for (int q = 0; q < 3; ++q)
+                    d[q] = *reinterpret_cast<const bf16x8*>(pa + q * WS_PS + j * 32 * WS_ROWB + ks * 32);
+            };
+            load_g(gv[0], 0);
+            load_a(av[0], 0, 0);
+#pragma unroll
+            for (int ks = 0; ks < WS_KC; ++ks) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int cur = (ks * 4 + j) & 1;
+                    if (j < 3) {
+                        load_a(av[cur ^ 1], ks, j + 1);
+                    } else if (ks + 1 < WS_KC) {
+                        load_g(gv[(ks + 1) & 1], ks + 1);
+                        load_a(av[cur ^ 1], ks + 1, 0);
+                    }
+#pragma unroll
+                    for (int sum = 4; sum >= 0; --sum)  // smallest partial products first
+#pragma unroll
+                        for (int p = 2; p >= 0; --p) {
+                            const int q = sum - p;
+                            if (q < 0 || q > 2) continue;
+                            if (TERMS == 8 && sum == 4) continue;
+                            if (TERMS == 6 && sum > 2) continue;
+                            acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(gv[ks & 1][p], av[cur][q], acc[j], 0, 0, 0);
+                        }
+                }
+            }
+            bsum = 0.f;
+            if (lh == 0) {  // bias: feature 4*l31 + mr, the 4-step groups in t order
+#pragma unroll
+                for (int q = 0; q < WS_NQ; ++q) bsum += myBias[q * 128 + 4 * l31 + mr];
+            }
+        };
+        auto store = [&](const Tile& x) {
+            const int m0 = x.tm * 128, n0 = x.tn * 128;
+            const int64_t b = x.s * 8 + xcd;
+            float sq = 0.f;
+            const auto rsW = make_rsrc(jobs.W[x.job] + b * gs_stride, (int64_t)out_f * ld_w * 4);
+            const int col = n0 + 4 * l31;
+            const unsigned row_bytes = (unsigned)ld_w * 4u;
+            unsigned soff = col < ld_w ? (unsigned)((m0 + mr + 16 * lh) * ld_w + col) * 4u : OOB;
+            if (DPK_K1_ABL & 1) soff = OOB;
+#pragma unroll
+            for (int q = 0; q < 16; ++q) {
+                const f32x4 v = {acc[0][q], acc[1][q], acc[2][q], acc[3][q]};
+                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), rsW, soff, 0, DPK_K1_STORE_AUX);
+                soff += ((q & 3) == 3 ? 20u : 4u) * row_bytes;  // slots 0 1 2 3 8 9 10 11 ... -> rows 4*slot
+                sq += v[0] * v[0];
+                sq += v[1] * v[1];
+                sq += v[2] * v[2];
+                sq += v[3] * v[3];
+            }
+            const float* GSb = jobs.Bi[x.job];
+            const bool has_bias = GSb != nullptr && x.tn == 0;
+            const auto rsB = make_rsrc(GSb + b * gs_stride, has_bias ? (int64_t)out_f * 4 : 0);
+            const int f = m0 + 4 * l31 + mr;
+            __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, bsum), rsB,
+                                                  lh == 0 ? (unsigned)f * 4u : OOB, 0, 0);
+            if (has_bias && lh == 0 && f < out_f) sq += bsum * bsum;
+            sq = wave_sum(sq);
+            if (lane == 0) red[g * 4 + mr] = sq;
+        };
+
+        lds_only_barrier();  // the loaders' prologue: A slice of the first tile group and G slice of tile 0 are staged
+        for (int n = 0; n <= N + 1; ++n) {
+            const Tile tc = locate(n), ts = locate(n - 1);
+            bool stored = false;
+            if (n > 0 && tc.ok && tc.tm == 0) {  // a new tile group begins: its A slice is staged in a phase of its own
+                if (((n - 1) & 1) == g) store(ts);
+                stored = true;
+                lds_only_barrier();
+            }
+            if ((n & 1) == g) {
+                if (tc.ok) contract(tc);
+            } else if (ts.ok && !stored) {
+                store(ts);
+            }
+            lds_only_barrier();
+        }
+        return;
+    }
+
+    // =================================== loaders ===================================
+    // Plain (compiler-tracked) buffer loads: a loader never stores a row, so the compiler's conservative wait before a
+    // staged register is read costs at most the tail of the OTHER set's loads, requested most of a phase earlier, and
+    // the loaders have slack (staging a slice takes about a quarter of a phase).
+    const int ptid = tid - WS_PROD0;
+    f32x4 rg[2][2][4];  // two sets; per lane two tasks of 4 steps x 4 columns (the second only for steps 32..47)
+    auto request = [&](f32x4 (&r)[2][4], const Tile& x, bool isG) {
+        const int64_t b = x.s * 8 + xcd;
+        const int job = x.ok ? x.job : 0;
+        const float* base = isG ? jobs.G[job] + b * T * ld_g : jobs.A[job] + b * T * in_f;
+        // rows at or past T lie beyond the descriptor: zeros; a tile past the last one fetches nothing
+        const int64_t bytes = !x.ok ? 0 : isG ? ((int64_t)(T - 1) * ld_g + out_f) * 4 : (int64_t)T * in_f * 4;
+        const auto rs = make_rsrc(base, bytes);
+        const int ld = isG ? ld_g : in_f;
+        const int dim = isG ? out_f : in_f;
+        const unsigned rowb = (unsigned)ld * 4u;
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+            const int idx = ptid + k * 256;
+            const int tq = idx >> 5;
+            const int col = (isG ? x.tm : x.tn) * 128 + (idx & 31) * 4;
+            unsigned off = (tq < WS_NQ && col < dim) ? (unsigned)((4 * tq) * ld + col) * 4u : OOB;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                r[k][i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, off, 0, 0));
+                off += rowb;
+            }
+        }
+    };
+    auto stage = [&](const f32x4 (&r)[2][4], const Tile& x, bool isG, unsigned char* img, float* bias) {
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+            const int idx = ptid + k * 256;
+            const int tq = idx >> 5;
+            const int cgp = idx & 31;
+            const int left = isG ? out_f - (x.tm * 128 + cgp * 4) : in_f - (x.tn * 128 + cgp * 4);
+            if (tq < WS_NQ) {
+                f32x4 v[4];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) v[i] = mask4(r[k][i], left);
+                if (isG) {
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) v[i] *= g_scale;
+                    *reinterpret_cast<f32x4*>(bias + tq * 128 + cgp * 4) = (v[0] + v[1]) + (v[2] + v[3]);
+                }
+                // column 4*cgp+e of the tile -> position e*32 + cgp (slot cgp of MFMA block e), for G and for A
+                unsigned char* dst = img + cgp * WS_ROWB + tq * 8;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    float x0 = v[0][e], x1 = v[1][e], x2 = v[2][e], x3 = v[3][e];
+                    unsigned char* d = dst + e * 32 * WS_ROWB;
+#pragma unroll
+                    for (int p = 0; p < 3; ++p) {
+                        const u32x2 w = {pack_bf16_rn(x0, x1), pack_bf16_rn(x2, x3)};
+                        *reinterpret_cast<u32x2*>(d + p * WS_PS) = w;
+                        if (p < 2) {
+                            x0 = rest_lo(x0, w[0]);
+                            x1 = rest_hi(x1, w[0]);
+                            x2 = rest_lo(x2, w[1]);
+                            x3 = rest_hi(x3, w[1]);
+                        }
+                    }
+                }
+            }
+            __builtin_amdgcn_sched_barrier(0);  // one task at a time: the two tasks' temporaries need not be live together
+        }
+    };
+    auto publish = [&](const Tile& x, int gsrc) {  // squared norm of a stored tile: the four waves' sums, in wave order
+        if (x.ok && ptid == 0) {
+            const float tot = ((red[gsrc * 4 + 0] + red[gsrc * 4 + 1]) + red[gsrc * 4 + 2]) + red[gsrc * 4 + 3];
+            const int64_t b = x.s * 8 + xcd;
+            normsq_part[b * part_stride + jobs.slot0[x.job] + x.tm * tiles_n + x.tn] = tot;
+        }
+    };
+
+    {   // prologue: the first tile group's A slice and tile 0's G slice staged, tiles 1 and 2 requested
+        const Tile t0 = locate(0);
+        request(rg[0], t0, true);
+        request(rg[1], t0, false);
+        stage(rg[1], t0, false, sA, nullptr);
+        stage(rg[0], t0, true, sG, sBias);
+        request(rg[1], locate(1), true);
+        request(rg[0], locate(2), true);
+        lds_only_barrier();
+    }
+    // Phase n: stage tile n+1's G slice (requested two phases ago) into the buffer of the group that is storing, then
+    // reuse its registers for tile n+3's — or, if tile n+1 opens a new tile group, for that group's A slice, which is
+    // staged in the extra phase before phase n+1 (and tile n+3's G slice is requested there); publish the squared norm
+    // of tile n-2, whose rows were stored in phase n-1.
+    auto phase = [&](f32x4 (&rs)[2][4], f32x4 (&ro)[2][4], int n) {  // rs: set (n+1) & 1, ro: set n & 1
+        const Tile tc = locate(n);
+        if (n > 0 && tc.ok && tc.tm == 0) {
+            stage(ro, tc, false, sA, nullptr);
+            request(ro, locate(n + 2), true);
+            lds_only_barrier();
+        }
+        const Tile nx = locate(n + 1);
+        if (nx.ok) {
+            const int gb = (n + 1) & 1;
+            stage(rs, nx, true, sG + gb * WS_IMG, sBias + gb * WS_NQ * 128);
+            if (nx.tm == 0) request(rs, nx, false);
+            else request(rs, locate(n + 3), true);
+        }
+        publish(locate(n - 2), n & 1);
+        lds_only_barrier();
+    };
+    for (int n = 0; n <= N + 1; n += 2) {
+        phase(rg[1], rg[0], n);
+        if (n + 1 <= N + 1) phase(rg[0], rg[1], n + 1);
+    }
+}
+
 inline int dpk_cu_count() {
     static int cached[64] = {0};
     int dev = 0;
@@ -1050,13 +1394,31 @@ constexpr int PERSIST_MAX_T = 48;
 // "split6" | "split8" | "split9" (bf16 pipe, that many exact partial products per fp32 product, any T).  Unset: the
 // faster of the two as measured: f32 up to 32 steps, where the kernel is store-bound either way and
 // the split's staging work only costs; split6 beyond, where the fp32 contraction is what the stores wait for.
-// Read at every launch (a getenv, ~0.1 us) so one process can time both.  Returns 0 for f32, else the term count.
+// Returns 0 for f32, else the term count.
+struct K1Knobs {
+    int mfma;  // -1: default; 0: f32; 6 / 8 / 9: split terms
+    int ws;    // role-split kernel for 32 < T <= 48 (default on)
+};
+inline K1Knobs& k1_knobs() {
+    // Process-wide; the initial values come from the environment, read ONCE (first K1 call of the process), and
+    // dpk_linear_configure() changes them afterwards.  Every choice meets the parity bar (tests run each).
+    static K1Knobs k = [] {
+        K1Knobs v = {-1, 1};
+        const char* e = getenv("DPK_K1_MFMA");
+        if (e && !strcmp(e, "split6")) v.mfma = 6;
+        if (e && !strcmp(e, "split8")) v.mfma = 8;
+        if (e && !strcmp(e, "split9")) v.mfma = 9;
+        if (e && !strcmp(e, "f32")) v.mfma = 0;
+        const char* w = getenv("DPK_K1_WS");
+        if (w && !strcmp(w, "0")) v.ws = 0;
+        return v;
+    }();
+    return k;
+}
 inline int k1_mode(int T) {
-    const char* e = getenv("DPK_K1_MFMA");
-    if (e && !strcmp(e, "split6")) return 6;
-    if (e && !strcmp(e, "split8")) return 8;
-    if (e && !strcmp(e, "split9")) return 9;
-    if (e && !strcmp(e, "f32")) return T <= PERSIST_MAX_T ? 0 : 6;
+    const int m = k1_knobs().mfma;
+    if (m > 0) return m;
+    if (m == 0) return T <= PERSIST_MAX_T ? 0 : 6;
     return T <= 32 ? 0 : 6;
 }
 
@@ -1078,6 +1440,16 @@ inline Plan pick_plan(int in_f, int out_f) {
 }
 
 }  // namespace
+
+extern "C" int dpk_linear_configure(int arithmetic, int role_split) {
+    if (arithmetic != -2 && arithmetic != -1 && arithmetic != 0 && arithmetic != 6 && arithmetic != 8 && arithmetic != 9)
+        return DPK_EINVAL;
+    if (role_split < -2 || role_split > 1) return DPK_EINVAL;
+    K1Knobs& k = k1_knobs();
+    if (arithmetic != -2) k.mfma = arithmetic;
+    if (role_split != -2) k.ws = role_split == 0 ? 0 : 1;
+    return DPK_OK;
+}
 
 extern "C" int dpk_linear_slots(int in_features, int out_features) {
     if (in_features <= 0 || out_features <= 0) return DPK_EINVAL;
@@ -1141,6 +1513,26 @@ int k1_launch(const float* const* A, const float* const* G, float* const* GSw, f
             // 32 < T <= 48: the A slice of a (sample, column tile) group stays in LDS for all its row tiles, and a
             // workgroup takes whole groups (no more workgroups than groups); otherwise it takes tiles
             const int kmode = T > PERSIST_MAX_T ? 1 : T > SPLIT_TC ? 2 : 0;
+            if (kmode == 2 && tiles_m >= 3 && k1_knobs().ws) {
+                // role-split kernel: one workgroup of 12 waves per CU (loaders + two contractor groups)
+                int64_t want = dpk_cu_count();
+                const int64_t groups = ((int64_t)(B + 7) / 8) * 8 * slot_cols * n_jobs;
+                if (want > groups) want = groups;
+                const dim3 pgrid((unsigned)((want + 7) / 8 * 8));
+#define DPK_K1_WS_GO(TERMSV)                                                                                      \
+    do {                                                                                                          \
+        auto kfn = linear_gs_ws_kernel<TERMSV>;                                                                   \
+        hipError_t e_ = hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, WS_LDS); \
+        if (e_ != hipSuccess) return (int)e_;                                                                     \
+        hipLaunchKernelGGL(kfn, pgrid, dim3(WS_THREADS), WS_LDS, s, jobs, normsq_part, part_stride, B, T, in_f,   \
+                           out_f, gs_stride, ld_w, ld_g, g_scale, tiles_m, slot_cols);                            \
+    } while (0)
+                if (mode == 6) DPK_K1_WS_GO(6);
+                else if (mode == 9) DPK_K1_WS_GO(9);
+                else DPK_K1_WS_GO(8);
+#undef DPK_K1_WS_GO
+                return dpk_launch_status();
+            }
             const int64_t units = ((int64_t)(B + 7) / 8) * 8 * slot_cols * n_jobs * (kmode == 2 ? 1 : tiles_m);
             int64_t want = 2 * (int64_t)dpk_cu_count();
             if (want > units) want = units;

@@ -65,13 +65,25 @@ int dpk_normsq_slots(int64_t P);
  * Arithmetic: fp32 in, fp32 out, fp32 accumulation in t order.  Small layers and sequences of up to 32 steps use
  * the fp32 matrix instruction; large layers (in > 128, out > 32) at T > 32 split each fp32 operand into three bf16
  * pieces (to 2^-27 of its value) and form 6 of the 9 exact partial products per fp32 product on the bf16 matrix pipe
- * (what is dropped is below 2^-26 of the product: a quarter of the fp32 product's own rounding).  The environment variable DPK_K1_MFMA = f32 | split6 | split8 | split9, read at every
- * call, overrides the choice (lab and A/B timing; k1_linear_gs.hip::k1_mode).
+ * (what is dropped is below 2^-26 of the product: a quarter of the fp32 product's own rounding).
+ * dpk_linear_configure() below overrides the choice.
  */
 int dpk_linear_grad_sample(const float* A, const float* G, float* GSw, float* GSb,
                            float* normsq_part, int64_t part_stride, int slot0,
                            int B, int T, int in_features, int out_features,
                            int64_t gs_stride, int ld_w, float g_scale, void* stream);
+
+/*
+ * Process-wide choice among K1's large-layer kernels (in > 128, out > 32); every choice meets the parity bar and the
+ * default is the fastest measured.  No counterpart in Opacus: its einsum has one arithmetic.
+ *   arithmetic  -1 default (fp32 matrix instruction up to 32 steps, 6 bf16 partial products beyond) | 0 fp32 matrix
+ *               instruction wherever it exists (T <= 48) | 6 | 8 | 9 partial products per fp32 product | -2 unchanged
+ *   role_split  1 (default): at 32 < T <= 48 and >= 3 row tiles the kernel with separate loader and contractor waves
+ *               (bit-identical to the other split kernel) | 0 off | -1 default | -2 unchanged
+ * Initial values: environment variables DPK_K1_MFMA = f32 | split6 | split8 | split9 and DPK_K1_WS = 0, read once at
+ * the first K1 call of the process.  Not to be called while launches of another thread are being issued.
+ */
+int dpk_linear_configure(int arithmetic, int role_split);
 
 /*
  * K1, grouped: n_jobs <= DPK_K1_MAX_JOBS layers of the SAME shape (B, T, in, out, ld_w) in one launch — the update /

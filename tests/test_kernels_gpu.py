@@ -18,6 +18,15 @@ def nat():
     return _native
 
 
+@pytest.fixture(autouse=True)
+def _k1_defaults():
+    """dpk_linear_configure is process-wide: every test starts from, and leaves, the defaults."""
+    yield
+    if torch.cuda.is_available():
+        from dp_timeautodiff_amd import _native
+        _native.linear_configure(arithmetic=None, role_split=None)
+
+
 def _arena(B, width, pad_front=64, pad_back=64):
     stride = pad_front + width + pad_back
     stride = (stride + 3) // 4 * 4
@@ -490,10 +499,7 @@ def test_linear_grad_sample_arithmetic_modes_are_fp32_accurate(nat, monkeypatch,
     ref_b = (G.double() * B).sum(1)
     errs = {}
     for mode in ("f32", "split6", "split8", "split9", None):
-        if mode is None:
-            monkeypatch.delenv("DPK_K1_MFMA", raising=False)
-        else:
-            monkeypatch.setenv("DPK_K1_MFMA", mode)
+        nat.linear_configure(arithmetic=mode)
         base = torch.zeros(B, ld * out_f + 64 * ((out_f + 63) // 64), device="cuda")
         part = torch.zeros(B, nat.linear_slots(in_f, out_f), device="cuda")
         nat.linear_grad_sample(A, G, nat.FlatView(base, 0, ld * out_f), nat.FlatView(base, ld * out_f, out_f), part, 0,
@@ -524,7 +530,7 @@ def test_linear_grad_sample_multi_equals_single_launches(nat, monkeypatch, B, ma
     """dpk_linear_grad_sample_multi (layers of different shapes in one launch: the small-batch path) against one
     dpk_linear_grad_sample call per layer on the fp32 matrix pipe: weights bit for bit for every layer; bias and
     squared-norm partials bit for bit for layers of the large plan (thinner layers sum the bias in another order)."""
-    monkeypatch.setenv("DPK_K1_MFMA", "f32")
+    nat.linear_configure(arithmetic="f32")
     if max_jobs:  # the host wrapper cuts longer job lists into several launches
         monkeypatch.setattr(nat, "K1_MULTI_MAX_JOBS", max_jobs)
     g = torch.Generator().manual_seed(B)
@@ -603,3 +609,57 @@ def test_linear_grad_sample_random_shapes(nat):
         nj = int(rs.choice([1, 1, 1, 2, 3]))
         bias = bool(rs.randint(0, 2))
         _arena_case(nat, B, T, in_f, out_f, nj, bias, seed=1000 + case)
+
+
+ROLE_SPLIT_CASES = [
+    # (B, T, in, out, n_jobs, ld_g_extra)  — all in the role-split kernel's range (32 < T <= 48, >= 3 row tiles of 128)
+    (37, 48, 250, 1000, 1, 0),     # the denoiser's ih/hh shape; B not a multiple of 8; ragged last row / column tile
+    (16, 48, 500, 1000, 1, 0),
+    (9, 33, 300, 385, 1, 0),       # T just above 32: steps 33..47 of the k-step padding are zeros; 4 row tiles, last of 1 row
+    (21, 41, 129, 512, 3, 1024),   # three jobs whose G are column blocks of one [B, T, 3*512] tensor (K8/K10 hand-over)
+    (300, 48, 256, 384, 2, 0),     # more (sample, column tile) groups than workgroups: every workgroup walks several
+]
+
+
+@pytest.mark.parametrize("B,T,in_f,out_f,nj,ldx", ROLE_SPLIT_CASES)
+def test_role_split_kernel_equals_split_kernel_bit_for_bit(nat, B, T, in_f, out_f, nj, ldx):
+    """linear_gs_ws_kernel (loader waves + two contractor groups, round 3) against linear_gs_split_kernel MODE 2 (every
+    wave does everything, round 2): same arithmetic per output element, so weights, bias, row padding and squared-norm
+    partials must agree bit for bit — and both against the float64 contraction at the fp32 bar."""
+    g = torch.Generator().manual_seed(B * 1000 + T)
+    ld_g = out_f + ldx if nj == 1 else out_f * nj
+    Gall = (torch.randn(B, T, ld_g if nj > 1 else out_f + ldx, generator=g) * 0.05).cuda()
+    As = [torch.randn(B, T, in_f, generator=g).cuda() for _ in range(nj)]
+    ld = (in_f + 31) // 32 * 32 if in_f % 32 else in_f
+    win = (ld * out_f + 63) // 64 * 64
+    bw = (out_f + 63) // 64 * 64
+    row = nj * (win + bw) + 64
+    slots = nat.linear_slots(in_f, out_f)
+    outs = {}
+    for split in (False, True):
+        nat.linear_configure(arithmetic="split6", role_split=split)
+        base = torch.full((B, row), 7.0, device="cuda")
+        part = torch.full((B, nj * slots + 3), -1.0, device="cuda")
+        jobs = []
+        for j in range(nj):
+            Gj = Gall[:, :, j * out_f:(j + 1) * out_f] if nj > 1 else Gall[:, :, :out_f]
+            jobs.append((As[j], Gj, nat.FlatView(base, j * (win + bw), ld * out_f),
+                         nat.FlatView(base, j * (win + bw) + win, out_f), j * slots))
+        nat.linear_grad_sample_group(jobs, part, float(B), ld_w=ld)
+        torch.cuda.synchronize()
+        outs[split] = (base, part)
+    assert torch.equal(outs[True][0], outs[False][0])
+    assert torch.equal(outs[True][1], outs[False][1])
+    base, part = outs[True]
+    assert float(base[:, -64:].min()) == 7.0 and float(part[:, -3:].max()) == -1.0      # nothing outside the windows
+    for j in range(nj):
+        Gj = (Gall[:, :, j * out_f:(j + 1) * out_f] if nj > 1 else Gall[:, :, :out_f]).double() * B
+        ref = torch.einsum("bto,bti->boi", Gj, As[j].double())
+        w = base[:, j * (win + bw):j * (win + bw) + ld * out_f].reshape(B, out_f, ld)
+        assert not w[:, :, in_f:].any()                                                # row padding: exact zeros
+        assert float(((w[:, :, :in_f].double() - ref).abs().amax((1, 2)) / ref.abs().amax((1, 2))).max()) < 1e-6
+        rb = Gj.sum(1)
+        b = base[:, j * (win + bw) + win:j * (win + bw) + win + out_f].double()
+        assert float(((b - rb).abs().amax(1) / rb.abs().amax(1)).max()) < 1e-6
+        sq = (ref ** 2).sum((1, 2)) + (rb ** 2).sum(1)
+        assert float((part[:, j * slots:(j + 1) * slots].double().sum(1) / sq - 1).abs().max()) < 1e-6

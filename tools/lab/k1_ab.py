@@ -73,7 +73,16 @@ def main():
         sl = (c_int * nj)(*[j * slots for j in range(nj)])
 
         def run(lib, name=None):
-            if name is not None and modes.get(name):
+            if name is not None and hasattr(lib, "dpk_linear_configure"):
+                # "lib.so@split8,ws0": arithmetic and / or role split through the library's own switch
+                arith, ws = -1, -1
+                for tok in filter(None, modes.get(name, "").split(",")):
+                    if tok in ("ws0", "ws1"):
+                        ws = int(tok[2])
+                    else:
+                        arith = {"f32": 0, "split6": 6, "split8": 8, "split9": 9}[tok]
+                lib.dpk_linear_configure(arith, ws)
+            elif name is not None and modes.get(name):
                 os.environ["DPK_K1_MFMA"] = modes[name]
             rc = lib.dpk_linear_grad_sample_group(pa, pg, pw, pb if args.bias else None, sl, nj, c_void_p(part.data_ptr()),
                                                   part.stride(0), B, T, in_f, out_f, row, ld, out_f, float(B), stream)
