@@ -76,6 +76,39 @@ def check_kernel(name, lines):
     return n_load, n_wait, per_copy, errors
 
 
+def check_private(name, lines, lo=120, hi=167):
+    """linear_gs_ws_kernel: v[lo..hi] belong to the loaders' inline assembly (the kernel is compiled with
+    amdgpu_num_vgpr(lo)); no instruction outside an ASMSTART/ASMEND block may name them.  Also lists the vector-memory
+    instructions in the text between consecutive hand-counted waits."""
+    errors, in_asm, vm, per = [], False, None, []
+    for ln, raw in lines:
+        if "ASMSTART" in raw:
+            in_asm = True
+            continue
+        if "ASMEND" in raw:
+            in_asm = False
+            continue
+        code, _, comment = raw.partition(";")
+        code = code.strip()
+        if not code or code.endswith(":") or code.startswith("."):
+            continue
+        op, _, rest = code.partition(" ")
+        if "DPK_PRIVWAIT" in comment:
+            if vm is not None:
+                per.append(vm)
+            vm = 0
+            continue
+        if op == "s_waitcnt" and "vmcnt" in rest and not in_asm:
+            errors.append(f"{name}:{ln}: compiler-inserted {code}")
+        if vm is not None and (op.startswith("buffer_") or op.startswith("global_") or op.startswith("flat_") or op.startswith("scratch_")):
+            vm += 1
+        if not in_asm:
+            bad = [r for r in regs(rest) if lo <= r <= hi]
+            if bad:
+                errors.append(f"{name}:{ln}: `{code}` names private register v{bad[0]}")
+    return per, errors
+
+
 def main():
     if len(sys.argv) > 1:
         path = sys.argv[1]
@@ -86,7 +119,7 @@ def main():
                        check=True, stderr=subprocess.DEVNULL)
     kernels, cur, name = {}, None, None
     for ln, raw in enumerate(open(path), 1):
-        m = re.match(r"^(_Z\w*linear_gs_split_kernel\w*):", raw)
+        m = re.match(r"^(_Z\w*linear_gs_(?:split|ws)_kernel\w*):", raw)
         if m:
             name, cur = m.group(1), []
             kernels[name] = cur
@@ -97,6 +130,15 @@ def main():
                 cur = None
     bad = 0
     for name, lines in kernels.items():
+        if "ws_kernel" in name:
+            per, errors = check_private(name, lines)
+            ws = re.search(r"ws_kernelILi(\d+)E", name)
+            print(f"ws<{ws.group(1)}>: vector-memory instructions in the text between hand-counted waits: {per}, "
+                  f"{len(errors)} problem(s)")
+            for e in errors[:12]:
+                print("   ", e)
+            bad += len(errors)
+            continue
         n_load, n_wait, per_copy, errors = check_kernel(name, lines)
         short = re.search(r"ILi(\d+)ELi(\d+)E", name)
         ws = re.search(r"ws_kernelILi(\d+)E", name)
