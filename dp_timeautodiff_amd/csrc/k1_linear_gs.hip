@@ -1317,49 +1317,59 @@ linear_gs_ws_kernel(
                     bsum = add_rn(bsum, add_rn(myBias[(2 * q) * 128 + 4 * l31 + mr], myBias[(2 * q + 1) * 128 + 4 * l31 + mr]));
             }
         };
-        auto store = [&](const Tile& x) {
+        // A tile's rows leave in two halves (accumulator registers 0-7, then 8-15 + bias + squared norm): normally back
+        // to back; where an extra phase (A slice of a new tile group) sits before the next contraction, one half in the
+        // extra phase and one beside that contraction, so that both phases have rows in the memory queue.
+        float sq = 0.f;
+        auto store_half = [&](const Tile& x, int half) {
             const int m0 = x.tm * 128, n0 = x.tn * 128;
             const int64_t b = x.s * 8 + xcd;
-            float sq = 0.f;
             const auto rsW = make_rsrc(jobs.W[x.job] + b * gs_stride, (int64_t)out_f * ld_w * 4);
             const int col = n0 + 4 * l31;
             const unsigned row_bytes = (unsigned)ld_w * 4u;
-            unsigned soff = col < ld_w ? (unsigned)((m0 + mr + 16 * lh) * ld_w + col) * 4u : OOB;
+            // slots 0 1 2 3 8 9 10 11 | 16 ... -> rows 4*slot: the second half starts 64 rows further
+            unsigned soff = col < ld_w ? (unsigned)((m0 + mr + 16 * lh + 64 * half) * ld_w + col) * 4u : OOB;
             if (DPK_K1_ABL & 1) soff = OOB;
+            if (half == 0) sq = 0.f;
 #pragma unroll
-            for (int q = 0; q < 16; ++q) {
-                const f32x4 v = {acc[0][q], acc[1][q], acc[2][q], acc[3][q]};
+            for (int q8 = 0; q8 < 8; ++q8) {
+                f32x4 v;
+                if (half == 0) v = f32x4{acc[0][q8], acc[1][q8], acc[2][q8], acc[3][q8]};
+                else v = f32x4{acc[0][q8 + 8], acc[1][q8 + 8], acc[2][q8 + 8], acc[3][q8 + 8]};
                 __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), rsW, soff, 0, DPK_K1_STORE_AUX);
-                soff += ((q & 3) == 3 ? 20u : 4u) * row_bytes;  // slots 0 1 2 3 8 9 10 11 ... -> rows 4*slot
+                soff += ((q8 & 3) == 3 ? 20u : 4u) * row_bytes;
                 sq = __builtin_fmaf(v[0], v[0], sq);
                 sq = __builtin_fmaf(v[1], v[1], sq);
                 sq = __builtin_fmaf(v[2], v[2], sq);
                 sq = __builtin_fmaf(v[3], v[3], sq);
             }
-            const float* GSb = jobs.Bi[x.job];
-            const bool has_bias = GSb != nullptr && x.tn == 0;
-            const auto rsB = make_rsrc(GSb + b * gs_stride, has_bias ? (int64_t)out_f * 4 : 0);
-            const int f = m0 + 4 * l31 + mr;
-            __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, bsum), rsB,
-                                                  lh == 0 ? (unsigned)f * 4u : OOB, 0, 0);
-            if (has_bias && lh == 0 && f < out_f) sq = __builtin_fmaf(bsum, bsum, sq);
-            sq = wave_sum(sq);
-            if (lane == 0) red[g * 4 + mr] = sq;
+            if (half == 1) {
+                const float* GSb = jobs.Bi[x.job];
+                const bool has_bias = GSb != nullptr && x.tn == 0;
+                const auto rsB = make_rsrc(GSb + b * gs_stride, has_bias ? (int64_t)out_f * 4 : 0);
+                const int f = m0 + 4 * l31 + mr;
+                __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, bsum), rsB,
+                                                      lh == 0 ? (unsigned)f * 4u : OOB, 0, 0);
+                if (has_bias && lh == 0 && f < out_f) sq = __builtin_fmaf(bsum, bsum, sq);
+                const float tot = wave_sum(sq);
+                if (lane == 0) red[g * 4 + mr] = tot;
+            }
         };
 
         lds_only_barrier();  // the loaders' prologue: A slice of the first tile group and G slice of tile 0 are staged
         Tile tc = first_tile(), ts = no_tile;  // tile n (contracted in phase n) and tile n-1 (stored in phase n)
         for (int n = 0; n <= N + 1; ++n) {
-            bool stored = false;
+            bool first_half_out = false;
             if (n > 0 && tc.ok && tc.tm == 0) {  // a new tile group begins: its A slice is staged in a phase of its own
-                if (((n - 1) & 1) == g) store(ts);
-                stored = true;
+                if (((n - 1) & 1) == g) store_half(ts, 0);
+                first_half_out = true;
                 lds_only_barrier();
             }
             if ((n & 1) == g) {
                 if (tc.ok) contract(tc);
-            } else if (ts.ok && !stored) {
-                store(ts);
+            } else if (ts.ok) {
+                if (!first_half_out) store_half(ts, 0);
+                store_half(ts, 1);
             }
             lds_only_barrier();
             ts = tc;
@@ -1377,6 +1387,8 @@ linear_gs_ws_kernel(
     // covered the set requested one phase ago made the loaders start staging at the END of their phase (measured with such
     // a wait: 1025 us against 742 with the staging skipped).
     const int ptid = tid - WS_PROD0;
+    // (s_setprio 2 for the loaders — each SIMD's youngest wave, last in line at equal priority — was measured slower:
+    // 956 / 1824 us against 948 / 1765 at 250 -> 1000 / 500 -> 1000, B = 4096)
     const int ngroups = N / tiles_m;
     const int P = N + 2 + (ngroups - 1);  // phases: one per tile, one extra per change of tile group, two to drain
     struct Slice {
@@ -1394,7 +1406,11 @@ linear_gs_ws_kernel(
         }
     };
     // A slice (48 steps x 128 columns) is 768 tasks of 2 steps x 4 columns: three per loader lane, 6 x 16 bytes in flight
-    // per lane and set.  Task idx = ptid + 256 k: step pair hq = idx >> 5 (0..23), column group cgp = idx & 31.
+    // per lane and set.  Lane l of loader wave w: column group cgp = (l & 7) + 8 w, step pairs hq = (l >> 3) + 8 k,
+    // k = 0..2.  The 32 lanes of an LDS-write group then hit 32 different banks (image rows are 28 dwords apart: 8 column
+    // groups x 4 step pairs; with 32 column groups per group it was 4 lanes per bank), and a load instruction still reads
+    // whole 128-byte lines (8 column groups of a row).
+    const int pcg = (ptid & 7) + 8 * (ptid >> 6), phq = (ptid >> 3) & 7;
     auto request = [&](auto set, const Slice& x) {
         const int64_t b = x.t.s * 8 + xcd;
         const int job = x.t.ok ? x.t.job : 0;
@@ -1404,19 +1420,19 @@ linear_gs_ws_kernel(
         const u32x4 rs = rsrc_words(base, bytes);
         const int ld = x.isG ? ld_g : in_f;
         const int dim = x.isG ? out_f : in_f;
-        const int col = (x.isG ? x.t.tm : x.t.tn) * 128 + (ptid & 31) * 4;
-        const unsigned off = col < dim ? (unsigned)((2 * (ptid >> 5)) * ld + col) * 4u : OOB;
+        const int col = (x.isG ? x.t.tm : x.t.tn) * 128 + pcg * 4;
+        const unsigned off = col < dim ? (unsigned)((2 * phq) * ld + col) * 4u : OOB;
         ws_load_set<decltype(set)::value>(rs, off, (unsigned)ld * 4u);  // an out-of-range offset stays out of range
     };
     auto stage = [&](const f32x4 (&r)[3][2], const Slice& x) {
-        const int cgp = ptid & 31;
+        const int cgp = pcg;
         const int left = x.isG ? out_f - (x.t.tm * 128 + cgp * 4) : in_f - (x.t.tn * 128 + cgp * 4);
         const float scale = x.isG ? g_scale : 1.0f;
         // column 4*cgp+e of the tile -> position e*32 + cgp (slot cgp of MFMA block e), for G and for A; step pair hq
         // is bytes 4*hq .. 4*hq+3 of the row
         const int gb = x.t.n & 1;
-        unsigned char* dst = (x.isG ? sG + gb * WS_IMG : sA) + cgp * WS_ROWB + (ptid >> 5) * 4;
-        float* bdst = sBias + gb * WS_NH * 128 + (ptid >> 5) * 128 + cgp * 4;
+        unsigned char* dst = (x.isG ? sG + gb * WS_IMG : sA) + cgp * WS_ROWB + phq * 4;
+        float* bdst = sBias + gb * WS_NH * 128 + phq * 128 + cgp * 4;
 #pragma unroll
         for (int k = 0; k < 3; ++k) {
             if (DPK_K1_ABL & 4) break;
