@@ -10,18 +10,19 @@ must equal --gpus or the run fails: a line that says n_gpus: N was measured on N
 
 A "step" is one complete DP-SGD training step on a resident synthetic batch: zero_grad, forward, loss, backward
 (hooks -> per-sample-gradient kernels K1/K3/K4), optimizer.step (K6 clip factors, K7 clipped sum + Philox noise +
-scale, then Adam K9).  Workload at N=1 = BASELINE.json configs[1] (VAE, B=1024, T=24, 32 features, hidden 128); with
-N>1 every rank runs the same per-GPU batch (weak scaling), the flat clipped sums are all-reduced once per step over
-RCCL and identical Philox noise is added on every rank.  `--config cfg4` = configs[3]: the VAE and the latent
-denoiser, 2048 samples per GPU through both.
+scale, then Adam K9).  Workload at N=1 = BASELINE.json configs[2], the LARGEST single-GPU configuration (latent
+diffusion denoiser, B=4096, T=48, per-sample clip over all 32 parameter groups; `--config cfg2` = configs[1], the VAE at
+B=1024, is measured in the same run under other_configs); with N>1 every rank runs the same per-GPU batch (weak
+scaling), the flat clipped sums are all-reduced once per step over RCCL and identical Philox noise is added on every
+rank.  `--config cfg4` = configs[3]: the VAE and the latent denoiser, 2048 samples per GPU through both.
 
 Printed JSON (rank 0, one line) also carries
   roofline       the kernel that is dominant BY TIME, K1 (per-sample-gradient contraction, all Linear layers of a
                  step): algorithmic bytes of its launches / their summed duration, HIP events on the launch stream;
   roofline_k7    the same for K7 (clip_reduce_noise, one pass over the arena);
   hot_path       K1..K7 alone, replayed from captured activations/backprops (no autograd, no Adam);
-  other_configs  (N=1, default config only) the same measurements, briefly, at cfg3 (largest single-GPU config) and
-                 cfg1 (the reference's own dp_job.sh shape);
+  other_configs  (N=1, default config only) the same measurements at cfg2 (configs[1]: VAE B=1024) and cfg1 (the
+                 reference's own dp_job.sh shape), with the headline's --steps / --warmup;
   dist           (N>1) backend, world size and RCCL version as torch.distributed reports them;
   cpu_baseline   the oracle's torch-CPU restatement of the reference step (per-call einsum + accumulate,
                  two-pass clip), timed on this box's host cores on a bounded sample of the same workload.
@@ -50,11 +51,11 @@ def parse(argv=None):
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--config", default="cfg2")
+    ap.add_argument("--config", default="cfg3")
     ap.add_argument("--batch", type=int, default=None, help="per-GPU batch (default: the config's)")
     ap.add_argument("--physical-batch", type=int, default=None, help="max physical chunk (BatchMemoryManager)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-other-configs", action="store_true", help="skip the brief cfg3 / cfg1 legs of the default run")
+    ap.add_argument("--no-other-configs", action="store_true", help="skip the cfg2 / cfg1 legs of the default run")
     ap.add_argument("--eager", action="store_true", help="launch every kernel from Python instead of replaying a hipGraph")
     ap.add_argument("--cpu-sample", type=int, default=None)
     ap.add_argument("--no-gemm-tuning", action="store_true",
@@ -362,12 +363,14 @@ def run_config(cfg, ctx, args, steps, warmup, batch=None, want_hot=True):
     # products (fp32 accumulate) on the bf16 pipe, whose peak in ALGORITHMIC fp32 flops is the bf16 peak / terms
     T_seq = max(workloads.CONFIGS[p.name]["T"] for p in parts)
     split = T_seq > 32 and os.environ.get("DPK_K1_MFMA", "") != "f32"
+    role_split = split and T_seq <= 48 and os.environ.get("DPK_K1_WS", "") != "0"
     mfma_peak = MFMA_BF16_PEAK_TFLOPS / K1_SPLIT_TERMS if split else MFMA_F32_PEAK_TFLOPS
     ridge = mfma_peak * 1e12 / (HBM_PEAK_GBS * 1e9)
     ai = B * flops / k1_bytes
     traffic = pmc_traffic(cfg, B, parts)
     roof = {"bound": "hbm" if ai < ridge else "mfma",
-            "kernel": ("linear_gs_split_kernel" if split else "linear_gs_persist_wide_kernel") + " / linear_gs_kernel "
+            "kernel": ("linear_gs_ws_kernel (>= 3 row tiles) / linear_gs_split_kernel" if role_split else
+                       "linear_gs_split_kernel" if split else "linear_gs_persist_wide_kernel") + " / linear_gs_kernel "
                       "(K1: per-sample-gradient contraction, every Linear layer of one step)",
             "arithmetic": (f"fp32 in/out, fp32 accumulate; products = {K1_SPLIT_TERMS} of the 9 exact partial products of a "
                            "3-way bf16 split (v_mfma_f32_32x32x16_bf16); dropped < 2^-26 of a product" if split else
@@ -375,18 +378,25 @@ def run_config(cfg, ctx, args, steps, warmup, batch=None, want_hot=True):
             "achieved": k1_gbs if ai < ridge else k1_tf, "peak": HBM_PEAK_GBS if ai < ridge else mfma_peak,
             "unit": "GB/s" if ai < ridge else "TFLOP/s",
             "frac": (k1_gbs / HBM_PEAK_GBS) if ai < ridge else (k1_tf / mfma_peak),
-            "traffic": traffic.get("k1"), "traffic_source": traffic.get("source"),
+            # `traffic` would be HBM bytes per step from PMC counters of THIS run; bench.py cannot collect them (that
+            # takes rocprofv3 --pmc passes of their own), so it is null and the figure of the committed passes over
+            # tools/hotpath_replay.py at this config is carried under its own name
+            "traffic": None, "traffic_committed": traffic.get("k1"), "traffic_source": traffic.get("source"),
             "ms_per_step": k1_total_ms, "launches_per_step": k1_launches,
             "avg_launch_ms": k1_total_ms / max(k1_launches, 1), "bytes_per_step": k1_bytes,
             "hbm_GBs": k1_gbs, "hbm_frac": k1_gbs / HBM_PEAK_GBS, "tflops": k1_tf,
             "mfma_frac": k1_tf / mfma_peak, "mfma_peak_tflops": mfma_peak, "flop_per_byte": ai}
     k7_ms = k7.mean_ms()
     k7_launches = len(k7.events) / n_timed
-    k7_bytes = sum(4.0 * p.gsm.arena.P * p.B for p in parts) / max(k7_launches, 1)  # arena read once per step
+    # algorithmic: every per-sample gradient element read once, 4 * P * B (the arena's row padding, ~2 % more at cfg3,
+    # is traffic the kernel really moves but not work the step asked for)
+    k7_bytes = sum(4.0 * p.wl.n_params * p.B for p in parts) / max(k7_launches, 1)
     roof7 = {"bound": "hbm", "kernel": "clip_reduce_kernel (K7: clipped sum + noise + scale)",
              "achieved": k7_bytes / (k7_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-             "frac": k7_bytes / (k7_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "traffic": traffic.get("k7"),
-             "traffic_source": traffic.get("source"), "avg_launch_ms": k7_ms, "bytes_per_launch": k7_bytes,
+             "frac": k7_bytes / (k7_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "traffic": None,
+             "traffic_committed": traffic.get("k7"), "traffic_source": traffic.get("source"),
+             "arena_bytes_per_launch": sum(4.0 * p.gsm.arena.P * p.B for p in parts) / max(k7_launches, 1),
+             "avg_launch_ms": k7_ms, "bytes_per_launch": k7_bytes,
              "launches_per_step": k7_launches}
 
     # ---- hot path alone: K1..K7 replayed from captured (activation, backprop) pairs ---------------------------
@@ -487,10 +497,10 @@ def main():
     }
     if dist is not None:
         out["dist"] = dist_info(dist)
-    if world == 1 and args.config == "cfg2" and args.batch is None and not args.no_other_configs:
-        # the largest single-GPU config (cfg3) and the reference's literal dp_job.sh shape (cfg1), briefly
+    if world == 1 and args.config == "cfg3" and args.batch is None and not args.no_other_configs:
+        # configs[1] (the VAE at B=1024) and the reference's literal dp_job.sh shape (cfg1), same steps / warm-up
         out["other_configs"] = {}
-        for name, (k, w) in (("cfg3", (3, 1)), ("cfg1", (20, 3))):
+        for name, (k, w) in (("cfg2", (args.steps, args.warmup)), ("cfg1", (max(args.steps, 20), args.warmup))):
             try:
                 out["other_configs"][name] = summary_of(run_config(name, ctx, args, k, w))
             except Exception as e:  # the headline line must survive a failure of an extra leg; the failure is reported

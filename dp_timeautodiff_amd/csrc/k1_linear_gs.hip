@@ -1195,14 +1195,17 @@ __device__ __forceinline__ void ws_read_set(f32x4 (&r)[3][2]) {
 // staged two phases after it was requested: the slot store of its own phase and the whole next phase are younger
 constexpr int WS_VM_YOUNGER = 1 + 6 + 1;
 
-template <int TERMS>
+template <int TERMS, bool SWAP>
 __global__ void __launch_bounds__(WS_THREADS) __attribute__((amdgpu_num_vgpr(WS_COMPILER_VGPRS)))
 linear_gs_ws_kernel(
     const K1Jobs jobs, float* __restrict__ normsq_part, int64_t part_stride, int B, int T, int in_f, int out_f,
     int64_t gs_stride, int ld_w, int ld_g, float g_scale, int tiles_m, int tiles_n) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_b[];
-    unsigned char* sA = smem_b;                           // [3][128][ROWB]   resident A slice of the current tile group
-    unsigned char* sG = smem_b + WS_IMG;                  // [2][3][128][ROWB] G slice of tile n in buffer n & 1
+    // A tile group is the tiles that share one RESIDENT slice: the row tiles of a (sample, column tile) with A resident
+    // (!SWAP), or — for layers with fewer than 3 row tiles — the column tiles of a (sample, row tile) with G resident
+    // (SWAP).  The other operand is STREAMED: one slice per tile.
+    unsigned char* sR = smem_b;                           // [3][128][ROWB]   resident slice of the current tile group
+    unsigned char* sS = smem_b + WS_IMG;                  // [2][3][128][ROWB] streamed slice of tile n in buffer n & 1
     float* sBias = reinterpret_cast<float*>(smem_b + 3 * WS_IMG);   // [2][WS_NH][128]: sums of 2 steps
     float* red = sBias + 2 * WS_NH * 128;                           // [2][4]
 
@@ -1210,10 +1213,11 @@ linear_gs_ws_kernel(
     const unsigned rank = blockIdx.x >> 3;
     const unsigned nbx = gridDim.x >> 3;
     const unsigned nsx = (unsigned)((B - xcd + 7) / 8);
-    const unsigned per_job = nsx * (unsigned)tiles_n;
+    const int tiles_in = SWAP ? tiles_n : tiles_m, tiles_out = SWAP ? tiles_m : tiles_n;  // per group / groups per sample
+    const unsigned per_job = nsx * (unsigned)tiles_out;
     const unsigned total_sg = per_job * (unsigned)jobs.n;   // (job, sample, column tile) groups of this XCD
     if (rank >= total_sg) return;                            // uniform
-    const int N = (int)((total_sg - rank + nbx - 1) / nbx) * tiles_m;   // tiles of this workgroup
+    const int N = (int)((total_sg - rank + nbx - 1) / nbx) * tiles_in;   // tiles of this workgroup
 
     // Tile n of this workgroup, as an iterator: the tile bookkeeping runs on the CU's ONE scalar unit for all 12 waves
     // (with a division-based "tile n -> (job, sample, row tile, column tile)" per use, a phase cost 150-360 scalar
@@ -1229,21 +1233,24 @@ linear_gs_ws_kernel(
         const unsigned U = x.ok ? x.U : 0u;
         x.job = (int)(U / per_job);
         const unsigned r = U - (unsigned)x.job * per_job;
-        x.s = (int)(r / (unsigned)tiles_n);
-        x.tn = (int)(r - (unsigned)x.s * (unsigned)tiles_n);
+        x.s = (int)(r / (unsigned)tiles_out);
+        const int outer = (int)(r - (unsigned)x.s * (unsigned)tiles_out);
+        if (SWAP) x.tm = outer;
+        else x.tn = outer;
     };
     auto first_tile = [&]() {
         Tile x;
         x.n = 0;
-        x.tm = 0;
+        x.tm = x.tn = 0;
         x.U = rank;
         group_of(x);
         return x;
     };
     auto advance = [&](Tile& x) {
         ++x.n;
-        if (++x.tm == tiles_m) {
-            x.tm = 0;
+        int& inner = SWAP ? x.tn : x.tm;
+        if (++inner == tiles_in) {
+            inner = 0;
             x.U += nbx;
             group_of(x);
         }
@@ -1259,8 +1266,8 @@ linear_gs_ws_kernel(
     if (wave < 8) {
         // ================================ contractors ================================
         const int g = wave >> 2, mr = wave & 3;
-        unsigned char* myG = sG + g * WS_IMG;
-        const float* myBias = sBias + g * WS_NH * 128;
+        unsigned char* myS = sS + g * WS_IMG;
+        const float* myBias = sBias + (SWAP ? 0 : g) * WS_NH * 128;  // the bias partials live with the G slice
         f32x16 acc[4];
         float bsum = 0.f;
 
@@ -1272,8 +1279,8 @@ linear_gs_ws_kernel(
             // Column block by column block (the 6 products of one accumulator back to back, smallest first: the order of
             // every accumulator's own chain is that of linear_gs_split_kernel), so that only one block's A operands and
             // the next block's are live: 48 operand registers instead of 60 + 60, which is what fits 168.
-            const unsigned char* pg = myG + (mr * 32 + l31) * WS_ROWB + lh * 16;
-            const unsigned char* pa = sA + l31 * WS_ROWB + lh * 16;
+            const unsigned char* pg = (SWAP ? sR : myS) + (mr * 32 + l31) * WS_ROWB + lh * 16;
+            const unsigned char* pa = (SWAP ? myS : sR) + l31 * WS_ROWB + lh * 16;
             bf16x8 gv[2][3], av[2][3];
             auto load_g = [&](bf16x8 (&d)[3], int ks) {
 #pragma unroll
@@ -1360,7 +1367,7 @@ linear_gs_ws_kernel(
         Tile tc = first_tile(), ts = no_tile;  // tile n (contracted in phase n) and tile n-1 (stored in phase n)
         for (int n = 0; n <= N + 1; ++n) {
             bool first_half_out = false;
-            if (n > 0 && tc.ok && tc.tm == 0) {  // a new tile group begins: its A slice is staged in a phase of its own
+            if (n > 0 && tc.ok && (SWAP ? tc.tn : tc.tm) == 0) {  // a new tile group: its resident slice has a phase of its own
                 if (((n - 1) & 1) == g) store_half(ts, 0);
                 first_half_out = true;
                 lds_only_barrier();
@@ -1389,19 +1396,19 @@ linear_gs_ws_kernel(
     const int ptid = tid - WS_PROD0;
     // (s_setprio 2 for the loaders — each SIMD's youngest wave, last in line at equal priority — was measured slower:
     // 956 / 1824 us against 948 / 1765 at 250 -> 1000 / 500 -> 1000, B = 4096)
-    const int ngroups = N / tiles_m;
+    const int ngroups = N / tiles_in;
     const int P = N + 2 + (ngroups - 1);  // phases: one per tile, one extra per change of tile group, two to drain
     struct Slice {
         Tile t;
-        bool isG;   // G slice of tile t (staged into buffer t.n & 1), else the A slice of t's tile group
+        bool streamed;   // the streamed slice of tile t (staged into buffer t.n & 1), else the resident slice of t's group
     };
     // The loaders' slices in phase order: G of tile 1, 2, ..., G of the first tile of the next tile group, that group's A
     // slice (its own, extra phase), G of the group's second tile, ...
     auto next_slice = [&](Slice& x) {
-        if (x.isG && x.t.ok && x.t.tm == 0) {
-            x.isG = false;  // same tile: its group's A slice
+        if (x.streamed && x.t.ok && (SWAP ? x.t.tn : x.t.tm) == 0) {
+            x.streamed = false;  // same tile: its group's resident slice
         } else {
-            x.isG = true;
+            x.streamed = true;
             advance(x.t);
         }
     };
@@ -1414,30 +1421,32 @@ linear_gs_ws_kernel(
     auto request = [&](auto set, const Slice& x) {
         const int64_t b = x.t.s * 8 + xcd;
         const int job = x.t.ok ? x.t.job : 0;
-        const float* base = x.isG ? jobs.G[job] + b * T * ld_g : jobs.A[job] + b * T * in_f;
+        const bool isG = x.streamed != SWAP;
+        const float* base = isG ? jobs.G[job] + b * T * ld_g : jobs.A[job] + b * T * in_f;
         // rows at or past T lie beyond the descriptor: zeros; a slice past the last one fetches nothing
-        const int64_t bytes = !x.t.ok ? 0 : x.isG ? ((int64_t)(T - 1) * ld_g + out_f) * 4 : (int64_t)T * in_f * 4;
+        const int64_t bytes = !x.t.ok ? 0 : isG ? ((int64_t)(T - 1) * ld_g + out_f) * 4 : (int64_t)T * in_f * 4;
         const u32x4 rs = rsrc_words(base, bytes);
-        const int ld = x.isG ? ld_g : in_f;
-        const int dim = x.isG ? out_f : in_f;
-        const int col = (x.isG ? x.t.tm : x.t.tn) * 128 + pcg * 4;
+        const int ld = isG ? ld_g : in_f;
+        const int dim = isG ? out_f : in_f;
+        const int col = (isG ? x.t.tm : x.t.tn) * 128 + pcg * 4;
         const unsigned off = col < dim ? (unsigned)((2 * phq) * ld + col) * 4u : OOB;
         ws_load_set<decltype(set)::value>(rs, off, (unsigned)ld * 4u);  // an out-of-range offset stays out of range
     };
     auto stage = [&](const f32x4 (&r)[3][2], const Slice& x) {
         const int cgp = pcg;
-        const int left = x.isG ? out_f - (x.t.tm * 128 + cgp * 4) : in_f - (x.t.tn * 128 + cgp * 4);
-        const float scale = x.isG ? g_scale : 1.0f;
+        const bool isG = x.streamed != SWAP;
+        const int left = isG ? out_f - (x.t.tm * 128 + cgp * 4) : in_f - (x.t.tn * 128 + cgp * 4);
+        const float scale = isG ? g_scale : 1.0f;
         // column 4*cgp+e of the tile -> position e*32 + cgp (slot cgp of MFMA block e), for G and for A; step pair hq
         // is bytes 4*hq .. 4*hq+3 of the row
         const int gb = x.t.n & 1;
-        unsigned char* dst = (x.isG ? sG + gb * WS_IMG : sA) + cgp * WS_ROWB + phq * 4;
-        float* bdst = sBias + gb * WS_NH * 128 + phq * 128 + cgp * 4;
+        unsigned char* dst = (x.streamed ? sS + gb * WS_IMG : sR) + cgp * WS_ROWB + phq * 4;
+        float* bdst = sBias + (SWAP ? 0 : gb) * WS_NH * 128 + phq * 128 + cgp * 4;
 #pragma unroll
         for (int k = 0; k < 3; ++k) {
             if (DPK_K1_ABL & 4) break;
             const f32x4 v0 = scale4_rn(mask4(r[k][0], left), scale), v1 = scale4_rn(mask4(r[k][1], left), scale);
-            if (x.isG) *reinterpret_cast<f32x4*>(bdst + k * 8 * 128) = add4_rn(v0, v1);
+            if (isG) *reinterpret_cast<f32x4*>(bdst + k * 8 * 128) = add4_rn(v0, v1);
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
                 float x0 = v0[e], x1 = v1[e];
@@ -1473,8 +1482,8 @@ linear_gs_ws_kernel(
     {   // prologue: the first tile group's A slice and tile 0's G slice staged; the slices of phases 0 and 1 requested
         Slice a0, g0;
         a0.t = g0.t = first_tile();
-        a0.isG = false;
-        g0.isG = true;
+        a0.streamed = false;   // (a0: the resident slice, g0: the streamed one — A and G when !SWAP)
+        g0.streamed = true;
         f32x4 r[3][2];
         request(S0, g0);
         request(S1, a0);
@@ -1484,7 +1493,7 @@ linear_gs_ws_kernel(
         ws_read_set<0>(r);
         stage(r, g0);
         st = g0;
-        st.isG = false;  // (so that the step below moves on to tile 1 instead of to tile 0's A slice)
+        st.streamed = false;  // (so that the step below moves on to tile 1 instead of to tile 0's resident slice)
         next_slice(st);  // phase 0 stages G of tile 1
         rq = st;
         request(S0, rq);
@@ -1505,7 +1514,7 @@ linear_gs_ws_kernel(
         // against 934 / 1772 at 250 -> 1000 / 500 -> 1000.)
         stage(r, st);
         request(set, rq);
-        const bool extra = !st.isG;   // an A slice is staged in the extra phase before its group's first contraction
+        const bool extra = !st.streamed;   // a resident slice is staged in the extra phase before its group's first tile
         publish(extra ? no_tile : pub2);
         lds_only_barrier();
         if (!extra) {
@@ -1659,15 +1668,18 @@ int k1_launch(const float* const* A, const float* const* G, float* const* GSw, f
             // 32 < T <= 48: the A slice of a (sample, column tile) group stays in LDS for all its row tiles, and a
             // workgroup takes whole groups (no more workgroups than groups); otherwise it takes tiles
             const int kmode = T > PERSIST_MAX_T ? 1 : T > SPLIT_TC ? 2 : 0;
-            if (kmode == 2 && tiles_m >= 3 && k1_knobs().ws) {
-                // role-split kernel: one workgroup of 12 waves per CU (loaders + two contractor groups)
+            if (kmode == 2 && (tiles_m >= 3 || slot_cols >= 3) && k1_knobs().ws) {
+                // role-split kernel: one workgroup of 12 waves per CU (loaders + two contractor groups).  A tile group =
+                // the row tiles of a column tile (A resident) if there are at least 3, else the column tiles of a row
+                // tile (G resident)
+                const bool swap = tiles_m < 3;
                 int64_t want = dpk_cu_count();
-                const int64_t groups = ((int64_t)(B + 7) / 8) * 8 * slot_cols * n_jobs;
+                const int64_t groups = ((int64_t)(B + 7) / 8) * 8 * (swap ? tiles_m : slot_cols) * n_jobs;
                 if (want > groups) want = groups;
                 const dim3 pgrid((unsigned)((want + 7) / 8 * 8));
 #define DPK_K1_WS_GO(TERMSV)                                                                                      \
     do {                                                                                                          \
-        auto kfn = linear_gs_ws_kernel<TERMSV>;                                                                   \
+        auto kfn = swap ? linear_gs_ws_kernel<TERMSV, true> : linear_gs_ws_kernel<TERMSV, false>;                 \
         hipError_t e_ = hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, WS_LDS); \
         if (e_ != hipSuccess) return (int)e_;                                                                     \
         hipLaunchKernelGGL(kfn, pgrid, dim3(WS_THREADS), WS_LDS, s, jobs, normsq_part, part_stride, B, T, in_f,   \

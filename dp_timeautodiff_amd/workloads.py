@@ -19,7 +19,7 @@ CONFIGS: Dict[str, dict] = {
     "cfg1_b50": dict(kind="vae", B=50, T=24, K=13, H=200, desc="VAE dp_job.sh literal batch 50"),
     "cfg2": dict(kind="vae", B=1024, T=24, K=32, H=128, cpu_sample=256,
                  desc="VAE encoder/decoder DP-SGD, B=1024 T=24 K=32 H=128"),
-    "cfg3": dict(kind="denoiser", B=4096, T=48, D=7, H=250, L=2, desc="latent diffusion denoiser DP-SGD, B=4096 T=48 H=250"),
+    "cfg3": dict(kind="denoiser", B=4096, T=48, D=7, H=250, L=2, cpu_sample=64, desc="latent diffusion denoiser DP-SGD, B=4096 T=48 H=250"),
     # configs[3]: both models under DP-SGD, global batch 16384 over 8 GPUs = 2048 per GPU through the VAE and the denoiser
     "cfg4": dict(kind="pair", parts=("cfg4_vae", "cfg4_den"), B=2048, cpu_sample=64,
                  desc="full VAE + latent diffusion denoiser DP-SGD, 2048 samples per GPU through both models "

@@ -612,12 +612,15 @@ def test_linear_grad_sample_random_shapes(nat):
 
 
 ROLE_SPLIT_CASES = [
-    # (B, T, in, out, n_jobs, ld_g_extra)  — all in the role-split kernel's range (32 < T <= 48, >= 3 row tiles of 128)
+    # (B, T, in, out, n_jobs, ld_g_extra)  — all in the role-split kernel's range (32 < T <= 48, >= 3 row or column tiles)
     (37, 48, 250, 1000, 1, 0),     # the denoiser's ih/hh shape; B not a multiple of 8; ragged last row / column tile
     (16, 48, 500, 1000, 1, 0),
     (9, 33, 300, 385, 1, 0),       # T just above 32: steps 33..47 of the k-step padding are zeros; 4 row tiles, last of 1 row
     (21, 41, 129, 512, 3, 1024),   # three jobs whose G are column blocks of one [B, T, 3*512] tensor (K8/K10 hand-over)
     (300, 48, 256, 384, 2, 0),     # more (sample, column tile) groups than workgroups: every workgroup walks several
+    (19, 48, 1000, 250, 1, 0),     # fewer than 3 row tiles: the G-resident form (tile group = column tiles of a row tile)
+    (70, 40, 400, 130, 2, 0),      # the same with a one-row-tile-and-a-bit layer, two jobs, T < 48
+    (300, 48, 640, 128, 1, 0),     # G-resident, ONE row tile, more groups than workgroups
 ]
 
 
