@@ -257,12 +257,22 @@ constexpr int MAX_DEVICES = 64;
 std::mutex scratch_mu;
 float* scratch_ptr[MAX_DEVICES] = {nullptr};
 
-// Device address of `scratch` on the CURRENT device (looked up once per device, with that device current).
-int scratch_for_current_device(float** out) {
+// Device address of `scratch` on the CURRENT device (looked up once per device, with that device current).  The
+// stream the kernels will run on must belong to that device: each GPU has its own copy of the array, and a stream of
+// another GPU would be handed this GPU's address.  The first call per device runs hipGetSymbolAddress (a lazy
+// code-object lookup): make it outside stream capture; once the address is cached the call is capture-safe
+// (tests/test_zz_no_alloc.py captures it into a hipGraph and replays it).
+int scratch_for_current_device(float** out, hipStream_t stream) {
     int dev = -1;
     hipError_t e = hipGetDevice(&dev);
     if (e != hipSuccess) return (int)e;
     if (dev < 0 || dev >= MAX_DEVICES) return DPK_ERANGE;
+    if (stream != nullptr) {  // the null stream is the current device's by definition
+        hipDevice_t sdev = -1;
+        e = hipStreamGetDevice(stream, &sdev);
+        if (e != hipSuccess) return (int)e;
+        if ((int)sdev != dev) return DPK_EINVAL;
+    }
     std::lock_guard<std::mutex> lock(scratch_mu);
     if (scratch_ptr[dev] == nullptr) {
         void* p = nullptr;
@@ -287,7 +297,7 @@ extern "C" int dpk_clip_reduce_noise_static(const float* GS, int64_t gs_stride, 
     if (need > (int64_t)DPK_STATIC_SCRATCH_BYTES) return DPK_ESCRATCH;
     float* ws = nullptr;
     if (need > 0) {  // the partials are fully overwritten before they are read: nothing to clear between calls
-        const int rc = scratch_for_current_device(&ws);
+        const int rc = scratch_for_current_device(&ws, (hipStream_t)stream);
         if (rc != DPK_OK) return rc;
     }
     return clip_reduce_impl(GS, gs_stride, clip, summed_in, noise, seed, offset, offset_dev, noise_std, inv_scale,

@@ -178,6 +178,12 @@ def switch_generator(*, data_loader: DataLoader, generator):
         prefetch_factor=data_loader.prefetch_factor, persistent_workers=data_loader.persistent_workers)
 
 
+class PoissonCapacityError(RuntimeError):
+    """A Poisson draw selected more samples than a fixed-capacity batch holds.  The samples beyond the capacity would
+    be dropped, i.e. the batch would no longer be a Poisson sample and the sampled-Gaussian accounting (every epsilon
+    the accountant reports) would not cover the run: an error, never a warning."""
+
+
 class DevicePoissonLoader:
     """Poisson-sampled batches drawn, compacted and gathered on the GPU (K11).
 
@@ -192,8 +198,10 @@ class DevicePoissonLoader:
       * `loader.sample_static()` — shape-static: returns the SAME `[capacity, ...]` tensors every call plus a device
         int32 `n_valid`; rows >= n_valid are padding (copies of sample 0) that `DPOptimizer.set_valid_rows(n_valid)`
         masks out with clip factor 0.  This is the form a hipGraph-captured step replays.
-    `capacity` defaults to expected + 8 sigma + 8 (overflow probability < 1e-14 per step); `overflow_steps()`
-    reports if a draw ever exceeded it (the excess samples of that step were dropped).
+    `capacity` defaults to expected + 8 sigma + 8 (overflow probability < 1e-14 per step).  A draw beyond it is never
+    silently truncated: the iterator form grows the capacity and repeats the SAME draw (same Philox position), the
+    shape-static form counts such draws on the device and `check_overflow()` — one host sync; `train.py` calls it once
+    per epoch, before epsilon is reported — raises `PoissonCapacityError`.
     """
 
     def __init__(self, tensors, *, sample_rate: float, device=None, capacity: Optional[int] = None,
@@ -222,17 +230,22 @@ class DevicePoissonLoader:
             capacity = int(exp + 8.0 * (exp * (1.0 - self.sample_rate)) ** 0.5 + 8)
         self.capacity = max(1, min(int(capacity), self.num_samples))
         import os
-        self.seed = int.from_bytes(os.urandom(8), "little") if seed is None else int(seed)  # the job's seed
+        self._graph_captured = False
+        self._seed = int.from_bytes(os.urandom(8), "little") if seed is None else int(seed)  # the job's seed
         self.device = device
         self._blocks_per_draw = (self.num_samples + 3) // 4
         self._offset_dev = torch.zeros(1, dtype=torch.int64, device=device)  # advanced on device: graph-replayable
-        self.idx = torch.zeros(self.capacity, dtype=torch.int64, device=device)
         self.counts = torch.zeros(2, dtype=torch.int32, device=device)
         self.n_valid = self.counts[0:1]
         self._overflow = torch.zeros(1, dtype=torch.int64, device=device)
-        self._static = [torch.empty((self.capacity,) + tuple(t.shape[1:]), dtype=t.dtype, device=device)
-                        for t in self.tensors]
+        self._allocate(self.capacity)
         self.dataset = torch.utils.data.TensorDataset(*self.tensors)  # PrivacyEngine reads len(loader.dataset)
+
+    def _allocate(self, capacity: int):
+        self.capacity = max(1, min(int(capacity), self.num_samples))
+        self.idx = torch.zeros(self.capacity, dtype=torch.int64, device=self.device)
+        self._static = [torch.empty((self.capacity,) + tuple(t.shape[1:]), dtype=t.dtype, device=self.device)
+                        for t in self.tensors]
 
     @classmethod
     def from_data_loader(cls, data_loader: DataLoader, *, device, seed: Optional[int] = None, capacity=None,
@@ -247,6 +260,18 @@ class DevicePoissonLoader:
 
     def __len__(self):
         return self.steps
+
+    @property
+    def seed(self) -> int:
+        return self._seed
+
+    @seed.setter
+    def seed(self, value: int):
+        if self._graph_captured and int(value) != self._seed:
+            # the sampler's Philox key is a by-value argument of the captured K11 launch, like the optimizer's noise key
+            raise RuntimeError("the sampler seed cannot change once its draws have been captured into a hipGraph: set it "
+                               "before GraphedDPStep.capture(), or capture again")
+        self._seed = int(value)
 
     @property
     def key(self) -> int:
@@ -268,8 +293,25 @@ class DevicePoissonLoader:
     def overflow_steps(self) -> int:
         return int(self._overflow.item())
 
+    def check_overflow(self):
+        """Raise if any shape-static draw so far selected more samples than `capacity` (one host sync)."""
+        n = self.overflow_steps()
+        if n:
+            raise PoissonCapacityError(
+                f"{n} Poisson draw(s) selected more than capacity = {self.capacity} samples and were truncated: the "
+                "steps taken are not Poisson-sampled DP-SGD steps and the accountant's epsilon does not cover them. "
+                "Re-run with a larger `capacity` (tensors captured into a hipGraph cannot grow).")
+
     def __iter__(self):
         for _ in range(self.steps):
             static, _ = self.sample_static()
-            n = int(self.counts[0].item())
+            n, selected = self.counts.tolist()  # the one host sync of the step
+            if selected > self.capacity:
+                # not a truncated batch: grow, and repeat the same draw from the same Philox position
+                self._allocate(int(selected * 1.25) + 8)
+                self._offset_dev.sub_(self._blocks_per_draw)
+                self._overflow.sub_(1)
+                static, _ = self.sample_static()
+                n, selected = self.counts.tolist()
+                assert selected <= self.capacity or self.capacity == self.num_samples
             yield [t[:n] for t in static]

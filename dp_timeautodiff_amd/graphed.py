@@ -98,15 +98,35 @@ class GraphedDPStep:
         gemm_tuning.freeze()  # the warm-up steps have tuned every GEMM shape of the step; no timing runs under capture
         capacity = self.module.arena.capacity
         hook, opt.step_hook = opt.step_hook, None  # host-side accounting happens per replay, not at capture
-        self.graph = torch.cuda.CUDAGraph()
-        try:
+        def capture_once(whole: bool):
+            self.graph = torch.cuda.CUDAGraph()
             # thread_local: a collective library's watchdog thread (RCCL) may query events while this thread captures;
             # in the default "global" mode that would invalidate the capture
             with torch.cuda.graph(self.graph, capture_error_mode="thread_local"):
-                self.static_loss = self._eager_step() if full else self._local_part()
+                self.static_loss = self._eager_step() if whole else self._local_part()
+
+        try:
+            try:
+                capture_once(full)
+            except Exception as e:  # noqa: BLE001
+                if not (self.distributed and full):
+                    raise
+                # the collective library refused capture (whole-step capture with RCCL inside has only run on a one-rank
+                # group so far): keep the communication-free part as the graph and run the exchange eagerly after each
+                # replay.  The optimizer's device-side noise offset and capturable Adam state work eagerly too.
+                import warnings
+                warnings.warn(f"capture of the data-parallel step with the all-reduce inside failed ({type(e).__name__}: "
+                              f"{e}); capturing the local part only, the exchange runs eagerly")
+                torch.cuda.synchronize()
+                opt.zero_grad(set_to_none=True)
+                full = False
+                capture_once(False)
         finally:
             opt.step_hook = hook
         self.exchange_captured = self.distributed and full
+        opt._graph_captured = True  # set_noise_state() refuses a different seed from here on (the key is baked in)
+        if self.loader is not None:
+            self.loader._graph_captured = True
         if self.module.arena.capacity != capacity:
             raise RuntimeError("the per-sample-gradient arena grew during capture; warm up with the capture batch size")
         return self

@@ -141,6 +141,11 @@ class DPOptimizer(Optimizer):
     def set_noise_state(self, seed: int, offset: int):
         """Restore the Philox stream position (checkpoints).  After enable_device_noise_offset() the live offset is
         the device word; the host-side offset stays 0 then."""
+        if getattr(self, "_graph_captured", False) and int(seed) != self.noise_seed:
+            # the Philox KEY is a by-value kernel argument baked into the captured graph (only the offset lives in a
+            # device word): a different seed would be reported by noise_state() and ignored by every replay
+            raise RuntimeError("the DP-noise seed cannot change once a step has been captured into a hipGraph: restore "
+                               "the checkpoint before GraphedDPStep.capture(), or capture again")
         self.noise_seed = int(seed)
         if self._noise_offset_dev is not None:
             self._noise_offset_dev.fill_(int(offset))

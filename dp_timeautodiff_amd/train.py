@@ -122,6 +122,7 @@ def train_dp_autoencoder(real_df, processed_data: torch.Tensor, channels: int, h
                     if batch_data[0].shape[0] > 0:
                         epoch_loss += loss_t.detach()
                         num_batches += 1
+        train_loader.check_overflow()  # a truncated Poisson draw voids the accounting: raise before epsilon is reported
         eps_now = privacy_engine.get_epsilon(delta)
         loss_val = float(loss_t.detach())
         losses.append(float(epoch_loss) / max(num_batches, 1))
@@ -140,8 +141,6 @@ def train_dp_autoencoder(real_df, processed_data: torch.Tensor, channels: int, h
                     "epoch": epoch + 1, "best_train_loss": best_train_loss, "patience": patience,
                     "beta": float(beta_t), "sampler_seed": train_loader.seed,
                     "sampler_offset": int(train_loader._offset_dev.item()), "loss": loss_val}})
-    if train_loader.overflow_steps():
-        log(f"warning: {train_loader.overflow_steps()} Poisson draws exceeded the sampler capacity and were truncated")
     ae.eval()
     with torch.no_grad():
         output, latent_features, mu_z, logvar_z = ae(processed_data.to(device))

@@ -211,6 +211,9 @@ int dpk_clip_reduce_noise(const float* GS, int64_t gs_stride, const float* clip,
  * DPK_ESCRATCH and launch nothing (with today's split rule the need never exceeds 13.1 MB).  All calls on one GPU share
  * that GPU's array: calls that overlap in time on one GPU (two streams, two threads) race — serialise them.  Nothing
  * has to be cleared between calls: every partial a call reads it has written itself.
+ * The device whose array is used is the CURRENT device, and `stream` must be one of its streams (another GPU's
+ * stream: DPK_EINVAL, nothing launched).  The FIRST call on a device performs the address lookup (hipGetSymbolAddress):
+ * make it outside stream capture, with that device current; every later call on that device is capture-safe.
  */
 #define DPK_STATIC_SCRATCH_BYTES (16 * 1024 * 1024)
 int dpk_clip_reduce_noise_static(const float* GS, int64_t gs_stride, const float* clip, const float* summed_in,

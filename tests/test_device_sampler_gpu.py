@@ -51,6 +51,30 @@ def test_loader_iterates_like_a_poisson_dataloader():
     assert len(set(seen)) > 1 and dl.overflow_steps() == 0
 
 
+def test_a_draw_beyond_the_capacity_is_never_silently_truncated():
+    """the iterator grows the capacity and repeats the same draw (every selected sample is yielded, the
+    Philox position of the next step is the one an untruncated run has); the shape-static form cannot grow (a hipGraph
+    holds its tensors), counts the overflow on the device and check_overflow() raises."""
+    from dp_timeautodiff_amd.data_loader import DevicePoissonLoader, PoissonCapacityError
+    from oracle import opacus_ref as O
+    N, q, seed = 5000, 0.2, 1                     # ~1000 selected per draw
+    labels = torch.arange(N)
+    blocks = (N + 3) // 4
+    dl = DevicePoissonLoader([labels], sample_rate=q, device="cuda", seed=seed, capacity=300, steps=3)
+    for k, (yb,) in enumerate(dl):
+        want = O.poisson_select(N, q, O.stream_key(seed, "sampler"), k * blocks)
+        assert len(want) > 300 and np.array_equal(yb.cpu().numpy(), want)
+    assert dl.capacity >= 1000 and dl.overflow_steps() == 0
+    dl.check_overflow()
+    st = DevicePoissonLoader([labels], sample_rate=q, device="cuda", seed=seed, capacity=300)
+    st.sample_static()
+    with pytest.raises(PoissonCapacityError, match="truncated"):
+        st.check_overflow()
+    ok = DevicePoissonLoader([labels], sample_rate=q, device="cuda", seed=seed, capacity=1400)
+    ok.sample_static()
+    ok.check_overflow()
+
+
 def _small_vae(dev, seed=0):
     from dp_timeautodiff_amd import models
     torch.manual_seed(seed)

@@ -457,3 +457,48 @@ def test_learning_rate_change_between_graph_replays_takes_effect():
     d3 = (replayed[3] - replayed[2]).abs().max()
     d2 = (replayed[2] - replayed[1]).abs().max()
     assert float(d3) < 0.6 * float(d2)                    # Adam's step size follows lr (3e-3 after 1e-2)
+
+
+@pytest.mark.gpu
+def test_seeds_cannot_change_under_a_captured_graph():
+    """the Philox keys (DP noise, device sampler) are by-value arguments of the captured launches.  Restoring
+    a DIFFERENT seed after capture would be reported by noise_state() and ignored by every replay: it raises; restoring
+    the same seed with another offset (what a checkpoint of the same job does) lands in the device word."""
+    from dp_timeautodiff_amd import models
+    from dp_timeautodiff_amd.data_loader import DevicePoissonLoader
+    from dp_timeautodiff_amd.grad_sample import GradSampleModule
+    from dp_timeautodiff_amd.graphed import GraphedDPStep
+    from dp_timeautodiff_amd.optimizer import DPOptimizer
+    dev = torch.device("cuda:0")
+    T, K = 6, 5
+    torch.manual_seed(1)
+    m = models.DeapStackDP(64, 16, T, 0, 0, K, [], K, 12, 1, 16, 8, 3).to(dev).train()
+    data = torch.rand(400, T, K)
+    loader = DevicePoissonLoader([data], sample_rate=0.05, device=dev, seed=5)
+    gsm = GradSampleModule(m)
+    opt = DPOptimizer(torch.optim.Adam(m.parameters(), lr=1e-3), noise_multiplier=0.7, max_grad_norm=0.05,
+                      expected_batch_size=20, noise_seed=99)
+    opt.attach_grad_sample_module(gsm)
+    opt.set_noise_state(98, 0)   # before capture: anything goes
+    opt.set_noise_state(99, 0)
+    loader.seed = 6
+    loader.seed = 5
+
+    def loss_fn(batch):
+        inner = gsm._module
+        inner.injected_eps = torch.zeros(batch[0].shape[0], T, 3, device=dev)
+        return models.vae_loss(gsm, batch[0])
+
+    step = GraphedDPStep(gsm, opt, loss_fn, warmup=2, loader=loader).capture()
+    step()
+    torch.cuda.synchronize()
+    with pytest.raises(RuntimeError, match="captured"):
+        opt.set_noise_state(7, 0)
+    with pytest.raises(RuntimeError, match="captured"):
+        loader.seed = 8
+    opt.set_noise_state(99, 4096)
+    loader.seed = 5
+    assert opt.noise_state() == {"seed": 99, "offset": 4096}
+    step()
+    torch.cuda.synchronize()
+    assert opt.noise_state()["offset"] == 4096 + gsm.arena.P // 4
