@@ -71,7 +71,10 @@ def main(argv=None):
         args.delta, args.max_grad_norm, args.save_path, args.load_path,
         max_physical_batch_size=args.max_physical_batch_size, accountant=args.accountant,
         use_graph=not args.no_graph, tune_gemms=args.tune_gemms, noise_seed=args.seed, sampler_seed=args.seed)
-    print(json.dumps({"epsilon_spent": out[7], "target_epsilon": args.epsilon, "seconds": round(time.time() - t0, 2),
+    rep = getattr(train_dp_autoencoder, "last_epsilon_report", {})
+    print(json.dumps({"epsilon_spent": out[7], "accountant": rep.get("accountant"),
+                      "rdp_epsilon_same_ledger": rep.get("rdp_epsilon"), "delta": rep.get("delta"),
+                      "target_epsilon": args.epsilon, "seconds": round(time.time() - t0, 2),
                       "samples": int(data.shape[0]), "epochs": args.n_epochs}))
 
 

@@ -21,6 +21,7 @@ MI355X-first differences (observable state after backward is the same: `p.grad_s
 """
 from __future__ import annotations
 
+import math
 import os
 from typing import Dict, Iterable, List, Optional, Tuple
 
@@ -449,12 +450,13 @@ class GradSampleModule(nn.Module):
         for t in tensors:
             if not batch_first and t.dim() >= 2 + feat_dims:
                 t = t.transpose(0, 1)
+            # explicit sizes: reshape(-1) is ambiguous for an empty Poisson batch (0 samples)
             if feat_dims == 0:
-                flat.append(t.reshape(t.shape[0], -1))
+                flat.append(t.reshape(t.shape[0], math.prod(t.shape[1:])))
             elif t.dim() == 2:
                 flat.append(t.unsqueeze(1))
             else:
-                flat.append(t.reshape(t.shape[0], -1, t.shape[-1]))
+                flat.append(t.reshape(t.shape[0], math.prod(t.shape[1:-1]), t.shape[-1]))
         if len(flat) == 1:
             return flat[0].contiguous()
         B = flat[0].shape[0]

@@ -27,7 +27,8 @@ def sine_cosine_features(v: torch.Tensor, num_terms: int = 8) -> torch.Tensor:
     ang = freqs * v.unsqueeze(-1)
     s = torch.sin(ang)
     c = torch.cos(ang)
-    return torch.cat((s.reshape(*s.shape[:-2], -1), c.reshape(*c.shape[:-2], -1)), dim=-1)
+    flat = s.shape[-2] * s.shape[-1]  # explicit: reshape(-1) is ambiguous for an EMPTY Poisson batch (0 samples)
+    return torch.cat((s.reshape(*s.shape[:-2], flat), c.reshape(*c.shape[:-2], flat)), dim=-1)
 
 
 class LinearCellGRU(nn.Module):

@@ -257,11 +257,14 @@ class DPOptimizer(Optimizer):
         self._advance_device_offset(arena, noise is None and std != 0)
         arena.summed_valid = True
 
+    def _step_without_backward(self):
+        """No backward pass since the last zero_grad: nothing to clip (upstream returns True here)."""
+        return True
+
     def pre_step(self, closure: Optional[Callable[[], float]] = None) -> Optional[float]:
         ps = self.params
         if not ps or all(getattr(p, "grad_sample", None) is None for p in ps) and not self.arena.pass_B:
-            # no backward pass since the last zero_grad: nothing to clip (upstream returns True here)
-            return True
+            return self._step_without_backward()
         arena, B = self._prepare()
         arena.ensure(max(B, 1))
         if self._check_skip_next_step():
@@ -379,6 +382,26 @@ class DistributedDPOptimizer(DPOptimizer):
     def _inv_scale(self) -> float:
         s = super()._inv_scale()
         return s / self.world_size if self.loss_reduction == "mean" else s
+
+    def _step_without_backward(self):
+        """A rank whose Poisson draw came out empty, and whose loop therefore ran no forward/backward, is still a
+        participant of the step's ONE collective: the other ranks are already waiting in the all-reduce.  It contributes
+        what it has accumulated (earlier physical chunks of this logical batch, else zeros) and takes the same noise and
+        scale as everyone.  Returning early here, as the single-process optimizer does, would hang the job."""
+        arena = self.arena
+        if self._check_skip_next_step():
+            self._is_last_step_skipped = True   # a non-final chunk with nothing in it: nothing to add, no exchange yet
+            return False
+        if not arena.summed_valid:
+            arena.summed.zero_()
+            arena.summed_valid = True
+        self._exchange_noise_scale(arena)
+        self._publish_summed(arena)
+        self._publish_grad(arena)
+        if self.step_hook:
+            self.step_hook(self)
+        self._is_last_step_skipped = False
+        return True
 
     def _reduce_noise_scale(self, arena, B):
         self._local_reduce(arena, B)

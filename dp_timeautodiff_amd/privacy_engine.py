@@ -198,6 +198,21 @@ class PrivacyEngine:
             self._eps_cache = (key, self.accountant.get_epsilon(delta))
         return self._eps_cache[1]
 
+    def epsilon_report(self, delta) -> Dict[str, Any]:
+        """The epsilon the engine's accountant reports AND the RDP bound of the same ledger.  PrivacyEngine() defaults to
+        the PRV accountant, as Opacus does (the reference's call, timeautoencoder.py:672): its epsilon is checked here as
+        a valid, tight bound by an independent composition (tests/test_prv_independent.py) but its equality with Opacus'
+        own PRV figure cannot be pinned offline; the RDP figure is the one pinned to Opacus' unit-test value."""
+        from .accountants import RDPAccountant
+        hist = list(getattr(self.accountant, "history", []))
+        key = (repr(hist), float(delta))
+        if getattr(self, "_rdp_cache", (None, None))[0] != key:
+            r = RDPAccountant()
+            r.history = hist
+            self._rdp_cache = (key, float(r.get_epsilon(delta)) if hist else 0.0)
+        return {"accountant": self.accountant.mechanism(), "epsilon": float(self.get_epsilon(delta)),
+                "rdp_epsilon": self._rdp_cache[1], "delta": float(delta)}
+
     # ---- checkpoints (unused by the reference; saves what its own save_autoencoder forgets) -----------
     def save_checkpoint(self, *, path: Union[str, os.PathLike, BinaryIO, IO[bytes]],
                         module: GradSampleModule, optimizer: Optional[DPOptimizer] = None,

@@ -123,10 +123,13 @@ def train_dp_autoencoder(real_df, processed_data: torch.Tensor, channels: int, h
                         epoch_loss += loss_t.detach()
                         num_batches += 1
         train_loader.check_overflow()  # a truncated Poisson draw voids the accounting: raise before epsilon is reported
-        eps_now = privacy_engine.get_epsilon(delta)
+        rep = privacy_engine.epsilon_report(delta)
+        eps_now = rep["epsilon"]
         loss_val = float(loss_t.detach())
         losses.append(float(epoch_loss) / max(num_batches, 1))
-        log(f"Epoch {epoch + 1}/{n_epochs} - Avg Loss: {losses[-1]:.4f} - eps: {eps_now:.2f}")
+        # which accountant produced the figure, and the RDP bound (the accountant pinned to Opacus' value) beside it
+        log(f"Epoch {epoch + 1}/{n_epochs} - Avg Loss: {losses[-1]:.4f} - eps: {eps_now:.2f} ({rep['accountant']}; "
+            f"rdp bound {rep['rdp_epsilon']:.2f})")
         if loss_val < best_train_loss:
             best_train_loss, patience = loss_val, 0
         else:
@@ -146,4 +149,5 @@ def train_dp_autoencoder(real_df, processed_data: torch.Tensor, channels: int, h
         output, latent_features, mu_z, logvar_z = ae(processed_data.to(device))
         recons_loss.append(float(sum(l for l in models.auto_loss(processed_data.to(device), output, n_bins, n_nums,
                                                                   n_cats, 0.0, cards))))
+    train_dp_autoencoder.last_epsilon_report = privacy_engine.epsilon_report(delta)  # the 8-tuple is the reference's
     return ae, latent_features.detach(), output, losses, recons_loss, mu_z, logvar_z, eps_now

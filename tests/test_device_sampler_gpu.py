@@ -75,6 +75,29 @@ def test_a_draw_beyond_the_capacity_is_never_silently_truncated():
     ok.check_overflow()
 
 
+def test_rank_shards_are_disjoint_exhaustive_and_independently_keyed():
+    """Data-parallel sampling: rank r of W owns samples r, r+W, ...; the shards partition the dataset,
+    every rank draws from its own Philox key, and the union of one step's draws is what the per-rank oracle streams
+    select — a Poisson sample of the whole dataset at the same rate."""
+    from dp_timeautodiff_amd.data_loader import DevicePoissonLoader
+    from oracle import opacus_ref as O
+    N, W, q, seed = 1003, 4, 0.05, 17   # N not a multiple of W
+    ids = torch.arange(N)
+    loaders = [DevicePoissonLoader([ids], sample_rate=q, device="cuda", seed=seed, rank=r, world_size=W) for r in range(W)]
+    owned = [l.tensors[0].cpu().numpy() for l in loaders]
+    assert sorted(np.concatenate(owned).tolist()) == list(range(N))          # disjoint and jointly exhaustive
+    assert all(np.array_equal(o, np.arange(r, N, W)) for r, o in enumerate(owned))
+    assert len({l.key for l in loaders}) == W                                # a stream per rank
+    drawn = []
+    for r, l in enumerate(loaders):
+        (yb,) = next(iter(l))
+        want_local = O.poisson_select(len(owned[r]), q, l.key, 0)
+        assert np.array_equal(yb.cpu().numpy(), owned[r][want_local])
+        drawn.append(yb.cpu().numpy())
+    allv = np.concatenate(drawn)
+    assert len(set(allv.tolist())) == len(allv)                              # no sample drawn by two ranks
+
+
 def _small_vae(dev, seed=0):
     from dp_timeautodiff_amd import models
     torch.manual_seed(seed)

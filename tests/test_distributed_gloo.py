@@ -92,3 +92,149 @@ def test_two_rank_step_equals_single_rank_step():
     assert (opt.per_sample_clip_factor < 1).any()
     err = np.abs(g0 - ref).max() / np.abs(ref).max()
     assert err < 1e-5, err
+
+
+def _spawn(fn, world=2, extra=()):
+    port = 29500 + ((os.getpid() * 7 + hash(fn.__name__)) % 2000)
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    mp.spawn(fn, args=(world, port, ret) + tuple(extra), nprocs=world, join=True)
+    return ret
+
+
+def _setup(rank, world, port):
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    torch.set_num_threads(2)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import cpu_backend
+    cpu_backend.install()
+
+
+def _empty_rank_worker(rank, world, port, ret, mode):
+    """Rank 1's Poisson draw is empty on a real step.  mode "skip": its loop runs no forward/backward at all (what a
+    loop with `if len(batch) == 0: continue`-style guards does) — it must still enter the all-reduce; mode "empty": it
+    runs forward/backward on zero-length tensors, as the reference's loop does."""
+    _setup(rank, world, port)
+    from dp_timeautodiff_amd import models
+    from dp_timeautodiff_amd.distributed import DifferentiallyPrivateDistributedDataParallel as DPDDP
+    from dp_timeautodiff_amd.grad_sample import GradSampleModule
+    from dp_timeautodiff_amd.optimizer import DistributedDPOptimizer
+    torch.manual_seed(7)
+    m = models.DeapStackDP(64, 8, 5, 0, 0, 4, [], 4, 10, 1, 8, 8, 3).train()
+    DPDDP(m)
+    gsm = GradSampleModule(m)
+    g = torch.Generator().manual_seed(9)
+    x = torch.rand(6, 5, 4, generator=g)
+    eps = torch.randn(6, 5, 3, generator=g)
+    opt = DistributedDPOptimizer(torch.optim.SGD(m.parameters(), lr=0.0), noise_multiplier=1.0, max_grad_norm=0.05,
+                                 expected_batch_size=3, noise_seed=77)
+    opt.attach_grad_sample_module(gsm)
+    steps = 0
+    opt.attach_step_hook(lambda o: None)
+    opt.zero_grad()
+    if rank == 0:
+        m.injected_eps = eps
+        models.vae_loss(gsm, x).backward()
+    elif mode == "empty":
+        m.injected_eps = eps[:0]
+        models.vae_loss(gsm, x[:0]).backward()
+    opt.step()  # rank 1 in "skip" mode: no backward ran — this call must not return before the exchange
+    ret[rank] = torch.cat([p.grad.reshape(-1) for p in m.parameters()]).numpy().copy()
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("mode", ["skip", "empty"])
+def test_rank_with_an_empty_poisson_batch_still_joins_the_exchange(mode):
+    ret = _spawn(_empty_rank_worker, extra=(mode,))
+    assert np.array_equal(ret[0], ret[1])
+    # = the single-process step on rank 0's six samples with the global expected batch (3 per rank x 2 ranks)
+    import cpu_backend
+    cpu_backend.install()
+    from dp_timeautodiff_amd import models
+    from dp_timeautodiff_amd.grad_sample import GradSampleModule
+    from dp_timeautodiff_amd.optimizer import DPOptimizer
+    torch.manual_seed(7)
+    m = models.DeapStackDP(64, 8, 5, 0, 0, 4, [], 4, 10, 1, 8, 8, 3).train()
+    gsm = GradSampleModule(m)
+    g = torch.Generator().manual_seed(9)
+    x = torch.rand(6, 5, 4, generator=g)
+    m.injected_eps = torch.randn(6, 5, 3, generator=g)
+    opt = DPOptimizer(torch.optim.SGD(m.parameters(), lr=0.0), noise_multiplier=1.0, max_grad_norm=0.05,
+                      expected_batch_size=6, noise_seed=77)
+    opt.attach_grad_sample_module(gsm)
+    opt.zero_grad()
+    models.vae_loss(gsm, x).backward()
+    opt.step()
+    ref = torch.cat([p.grad.reshape(-1) for p in m.parameters()]).numpy()
+    assert np.abs(ret[0] - ref).max() / np.abs(ref).max() < 1e-5
+
+
+def _two_model_worker(rank, world, port, ret):
+    """BASELINE configs[3] in miniature: a VAE and a denoiser, each with its own arena and optimizer, two flat
+    all-reduces per step (bench.py's `Part` x 2), over two steps so that both noise streams advance."""
+    _setup(rank, world, port)
+    from dp_timeautodiff_amd import models
+    from dp_timeautodiff_amd.distributed import DifferentiallyPrivateDistributedDataParallel as DPDDP
+    from dp_timeautodiff_amd.grad_sample import GradSampleModule
+    from dp_timeautodiff_amd.optimizer import DistributedDPOptimizer
+    out = _two_model_steps(rank, world, models, GradSampleModule,
+                           lambda o, per: DistributedDPOptimizer(o, noise_multiplier=0.8, max_grad_norm=0.05,
+                                                                 expected_batch_size=per, noise_seed=31 + rank),
+                           wrap=DPDDP)
+    ret[rank] = out
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def _two_model_steps(rank, world, models, GSM, make_opt, wrap=None):
+    B, T = 8, 5
+    per = B // world
+    lo = rank * per
+    g = torch.Generator().manual_seed(3)
+    x = torch.rand(B, T, 4, generator=g)
+    eps = torch.randn(B, T, 3, generator=g)
+    xn, noise = torch.randn(B, T, 3, generator=g), torch.randn(B, T, 3, generator=g)
+    t = torch.rand(B, T, 1, generator=g).sort(1)[0]
+    i = torch.randint(0, 100, (B, 1, 1), generator=g).float().expand(B, T, 1).contiguous()
+    ti = torch.rand(B, T, 8, generator=g)
+    torch.manual_seed(50 + rank)
+    vae = models.DeapStackDP(64, 8, T, 0, 0, 4, [], 4, 10, 1, 8, 8, 3).train()
+    den = models.BiRNNScoreDP(3, 8, 1, 100).train()
+    if wrap is not None:
+        wrap(vae)
+        wrap(den)
+    gv, gd = GSM(vae), GSM(den)
+    ov = make_opt(torch.optim.SGD(vae.parameters(), lr=0.05), per)
+    od = make_opt(torch.optim.SGD(den.parameters(), lr=0.05), per)
+    ov.attach_grad_sample_module(gv)
+    od.attach_grad_sample_module(gd)
+    sl = slice(lo, lo + per)
+    for _ in range(2):
+        ov.zero_grad()
+        vae.injected_eps = eps[sl]
+        models.vae_loss(gv, x[sl]).backward()
+        ov.step()
+        od.zero_grad()
+        models.denoiser_loss(gd, xn[sl], t[sl], i[sl], ti[sl], noise[sl]).backward()
+        od.step()
+    return [torch.cat([p.detach().reshape(-1) for p in m.parameters()]).numpy().copy() for m in (vae, den)]
+
+
+def test_two_models_two_flat_allreduces_per_step():
+    ret = _spawn(_two_model_worker)
+    for k in range(2):
+        assert np.array_equal(ret[0][k], ret[1][k]), "both ranks must hold identical parameters after the steps"
+    import cpu_backend
+    cpu_backend.install()
+    from dp_timeautodiff_amd import models
+    from dp_timeautodiff_amd.grad_sample import GradSampleModule
+    from dp_timeautodiff_amd.optimizer import DPOptimizer
+    ref = _two_model_steps(0, 1, models, GradSampleModule,
+                           lambda o, per: DPOptimizer(o, noise_multiplier=0.8, max_grad_norm=0.05,
+                                                      expected_batch_size=per, noise_seed=31))
+    for k in range(2):
+        assert np.abs(ret[0][k] - ref[k]).max() / np.abs(ref[k]).max() < 1e-5, k

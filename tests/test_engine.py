@@ -337,6 +337,34 @@ def test_empty_poisson_batch_gives_pure_noise(dev):
     assert np.abs(net[0].weight.grad.cpu().reshape(-1).numpy() - z[w.offset:w.offset + 12]).max() < 1e-5
 
 
+def test_empty_poisson_batch_flows_through_the_vae(dev):
+    """A Poisson draw of zero samples reaches the model as [0, T, K] tensors (the reference's loop does not guard it,
+    timeautoencoder.py:731-751): forward, loss, backward and step must run — fused recurrence included on the HIP
+    backend — and the step is pure noise."""
+    from dp_timeautodiff_amd import models
+    from dp_timeautodiff_amd.grad_sample import GradSampleModule
+    from dp_timeautodiff_amd.optimizer import DPOptimizer
+    torch.manual_seed(0)
+    m = models.DeapStackDP(64, 8, 5, 0, 0, 4, [], 4, 16, 1, 8, 8, 3).to(dev).train()
+    if dev.type == "cuda":
+        from dp_timeautodiff_amd.layers.fused_gru import fuse_recurrences
+        m = fuse_recurrences(m)
+    gsm = GradSampleModule(m)
+    opt = DPOptimizer(torch.optim.SGD(m.parameters(), lr=0.1), noise_multiplier=1.0, max_grad_norm=2.0,
+                      expected_batch_size=4, noise_seed=11)
+    opt.attach_grad_sample_module(gsm)
+    opt.zero_grad()
+    m.injected_eps = torch.zeros(0, 5, 3, device=dev)
+    models.vae_loss(gsm, torch.zeros(0, 5, 4, device=dev)).backward()
+    opt.step()
+    from oracle import opacus_ref as O
+    z = O.philox_normal(opt.arena.P, O.stream_key(11, "noise"), 0, 2.0) / 4.0
+    for p in m.parameters():
+        w = opt.arena.window(p)
+        got = opt.arena.grad[w.offset:w.offset + w.numel].cpu().numpy()
+        assert np.abs(got - z[w.offset:w.offset + w.numel]).max() < 1e-5
+
+
 def test_optimizer_keys_its_kernel_with_the_derived_noise_key(dev):
     from dp_timeautodiff_amd import rng
     from dp_timeautodiff_amd.grad_sample import GradSampleModule
