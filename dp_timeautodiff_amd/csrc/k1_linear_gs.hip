@@ -699,6 +699,15 @@ __device__ __forceinline__ unsigned pack_bf16_rn(float lo, float hi) {
     asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(r) : "v"(lo), "v"(hi));
     return r;
 }
+// First piece of a pair: the operand is clamped to the largest finite bf16 (0x7F7F0000 = 3.3895e38) before it is rounded.
+// Round-to-nearest takes a finite fp32 above 3.3961e38 to bf16 infinity; the remainder would then be -inf and every
+// product NaN where the fp32 instruction gives a finite number.  Clamped, the piece is the largest finite bf16, the
+// remainder (< 2^120) is exact and the split stays exact up to FLT_MAX.  An infinite operand becomes {max, inf, NaN}: its
+// products are NaN (the fp32 instruction gives +-inf or NaN); a NaN operand stays NaN through the remainders.
+__device__ __forceinline__ unsigned pack_bf16_first(float lo, float hi) {
+    const float M = __builtin_bit_cast(float, 0x7F7F0000u);
+    return pack_bf16_rn(__builtin_amdgcn_fmed3f(lo, -M, M), __builtin_amdgcn_fmed3f(hi, -M, M));
+}
 // what the pair's two bf16 values leave of lo / hi: exact differences (the operands are within a factor of two)
 __device__ __forceinline__ float rest_lo(float lo, unsigned pk) { return lo - __builtin_bit_cast(float, pk << 16); }
 __device__ __forceinline__ float rest_hi(float hi, unsigned pk) { return hi - __builtin_bit_cast(float, pk & 0xffff0000u); }
@@ -913,7 +922,8 @@ __global__ void __launch_bounds__(256, 2) linear_gs_split_kernel(
                     unsigned char* d = dst + e * 32 * rowb;
 #pragma unroll
                     for (int p = 0; p < 3; ++p) {
-                        const u32x2 w = {pack_bf16_rn(x0, x1), pack_bf16_rn(x2, x3)};
+                        const u32x2 w = p == 0 ? u32x2{pack_bf16_first(x0, x1), pack_bf16_first(x2, x3)}
+                                               : u32x2{pack_bf16_rn(x0, x1), pack_bf16_rn(x2, x3)};
                         *reinterpret_cast<u32x2*>(d + p * pstride) = w;
                         if (p < 2) {
                             x0 = rest_lo(x0, w[0]);
@@ -1453,7 +1463,7 @@ linear_gs_ws_kernel(
                 unsigned char* d = dst + k * 32 + e * 32 * WS_ROWB;
 #pragma unroll
                 for (int p = 0; p < 3; ++p) {
-                    const unsigned w = pack_bf16_rn(x0, x1);
+                    const unsigned w = p == 0 ? pack_bf16_first(x0, x1) : pack_bf16_rn(x0, x1);
                     *reinterpret_cast<unsigned*>(d + p * WS_PS) = w;
                     if (p < 2) {
                         x0 = rest_lo(x0, w);

@@ -666,3 +666,115 @@ def test_role_split_kernel_equals_split_kernel_bit_for_bit(nat, B, T, in_f, out_
         assert float(((b - rb).abs().amax(1) / rb.abs().amax(1)).max()) < 1e-6
         sq = (ref ** 2).sum((1, 2)) + (rb ** 2).sum(1)
         assert float((part[:, j * slots:(j + 1) * slots].double().sum(1) / sq - 1).abs().max()) < 1e-6
+
+
+# ---- special values through the bf16-split arithmetic ------------------------------------------------
+def _k1_run(nat, A, G, mode, role_split, g_scale=1.0):
+    B, T, in_f = A.shape
+    out_f = G.shape[2]
+    ld = (in_f + 31) // 32 * 32 if in_f % 32 else in_f
+    nat.linear_configure(arithmetic=mode, role_split=role_split)
+    base = torch.zeros(B, ld * out_f + 64 * ((out_f + 63) // 64), device="cuda")
+    part = torch.zeros(B, nat.linear_slots(in_f, out_f), device="cuda")
+    nat.linear_grad_sample(A, G, nat.FlatView(base, 0, ld * out_f), nat.FlatView(base, ld * out_f, out_f), part, 0,
+                           g_scale, ld_w=ld)
+    torch.cuda.synchronize()
+    return base[:, :ld * out_f].reshape(B, out_f, ld)[:, :, :in_f].clone(), base[:, ld * out_f:ld * out_f + out_f].clone(), part
+
+
+# (T, in, out): role-split kernel / split kernel MODE 2 at T = 48, the T > 48 split kernel (MODE 1) at T = 80
+SPECIAL_SHAPES = [(48, 256, 384), (80, 256, 256)]
+
+
+def _special_modes(T):
+    modes = [("split6", True), ("split6", False), ("split9", False)]
+    if T <= 48:
+        modes.append(("f32", False))
+    return modes
+
+
+@pytest.mark.parametrize("T,in_f,out_f", SPECIAL_SHAPES)
+def test_split_arithmetic_near_flt_max(nat, T, in_f, out_f):
+    """Operands between the largest finite bf16 (3.3895e38) and FLT_MAX (3.4028e38): rounding the first piece to nearest
+    would give bf16 infinity and NaN products; the clamped first piece keeps the split exact.  One large term per
+    output element (the rest of the sequence is zero) so that the exact result is finite: 1.7e38."""
+    B = 8
+    big = 3.4e38
+    g = torch.Generator().manual_seed(1)
+    G = torch.zeros(B, T, out_f)
+    A = torch.zeros(B, T, in_f)
+    t0 = torch.randint(0, T, (B,), generator=g)
+    sign = torch.where(torch.rand(B, out_f, generator=g) < 0.5, -1.0, 1.0)
+    for b in range(B):
+        G[b, t0[b]] = big * sign[b]
+        A[b, t0[b]] = 0.5 * (1 + torch.arange(in_f) % 2 * -0.25)   # 0.5 / 0.375
+    ref = torch.einsum("bto,bti->boi", G.double(), A.double())
+    assert float(ref.abs().max()) < 3.4e38
+    for mode, rs in _special_modes(T):
+        w, b, part = _k1_run(nat, A.cuda(), G.cuda(), mode, rs)
+        assert torch.isfinite(w).all(), (mode, rs)
+        assert float(((w.double().cpu() - ref).abs() / ref.abs().clamp_min(1e30)).max()) < 1e-6, (mode, rs)
+        assert float((b.double().cpu() - G.double().sum(1)).abs().max()) == 0.0   # one term per row: exact
+
+
+@pytest.mark.parametrize("T,in_f,out_f", SPECIAL_SHAPES)
+def test_split_arithmetic_inf_and_nan_stay_where_they_are(nat, T, in_f, out_f):
+    """An infinite backprop entry poisons its own row of its own sample (non-finite: the split forms NaN where the fp32
+    instruction forms +-inf), a NaN activation its own column; every other output element equals the clean run bit for
+    bit in every mode."""
+    B = 8
+    g = torch.Generator().manual_seed(2)
+    A = torch.randn(B, T, in_f, generator=g)
+    G = torch.randn(B, T, out_f, generator=g) * 0.1
+    Ab, Gb = A.clone(), G.clone()
+    Gb[3, T // 2, 200] = float("inf")
+    Gb[5, 1, 7] = float("-inf")
+    Ab[6, T - 1, 129] = float("nan")
+    for mode, rs in _special_modes(T):
+        w0, b0, p0 = _k1_run(nat, A.cuda(), G.cuda(), mode, rs, g_scale=float(B))
+        w1, b1, p1 = _k1_run(nat, Ab.cuda(), Gb.cuda(), mode, rs, g_scale=float(B))
+        bad = torch.zeros_like(w0, dtype=torch.bool)
+        bad[3, 200, :] = True
+        bad[5, 7, :] = True
+        bad[6, :, 129] = True
+        assert not torch.isfinite(w1[bad]).any(), (mode, rs)
+        assert torch.equal(w1[~bad], w0[~bad]), (mode, rs)
+        assert not torch.isfinite(b1[3, 200]) and not torch.isfinite(b1[5, 7])
+        clean = torch.ones_like(b0, dtype=torch.bool)
+        clean[3, 200] = clean[5, 7] = False
+        assert torch.equal(b1[clean], b0[clean])
+        # the poisoned samples' squared norms are non-finite, the others' untouched
+        s0, s1 = p0.sum(1), p1.sum(1)
+        assert not torch.isfinite(s1[[3, 5, 6]]).any() and torch.equal(s1[[0, 1, 2, 4, 7]], s0[[0, 1, 2, 4, 7]])
+
+
+@pytest.mark.parametrize("T,in_f,out_f", SPECIAL_SHAPES)
+def test_split_arithmetic_zeros_subnormals_and_dynamic_range(nat, T, in_f, out_f):
+    B = 8
+    g = torch.Generator().manual_seed(3)
+    A = torch.randn(B, T, in_f, generator=g)
+    G = torch.randn(B, T, out_f, generator=g)
+    # sample 0: all-zero backprops; sample 1: negative zeros; sample 2: rows 10..19 zero; sample 3: scaled so that
+    # g_scale * G is SUBNORMAL (1e-39 .. 1e-41); samples 4..7: twelve decades across t within every column
+    G[0] = 0.0
+    G[1] = -0.0
+    G[2, :, 10:20] = 0.0
+    G[3] *= 1e-40
+    decades = 10.0 ** torch.linspace(-6, 6, T)
+    G[4:] *= decades[None, :, None]
+    ref = torch.einsum("bto,bti->boi", G.double(), A.double())
+    tiny = 2.0 ** -126
+    for mode, rs in _special_modes(T):
+        w, b, part = _k1_run(nat, A.cuda(), G.cuda(), mode, rs)
+        w = w.double().cpu()
+        assert torch.isfinite(w).all()
+        assert not w[0].any() and not w[1].any() and not w[2, 10:20].any(), (mode, rs)
+        assert float(part[0].abs().max()) == 0.0 and float(part[1].abs().max()) == 0.0
+        # subnormal operands may be flushed by the matrix pipes (either of them): what can be lost is at most one
+        # smallest-normal-sized product per step
+        assert float((w[3] - ref[3]).abs().max()) <= T * tiny * float(A[3].abs().max()), (mode, rs)
+        # dynamic range: every column on its own scale
+        err = ((w[4:] - ref[4:]).abs().amax(1) / ref[4:].abs().amax(1)).max()
+        assert float(err) < 1e-6, (mode, rs, float(err))
+        err2 = ((w[2] - ref[2]).abs().amax(0) / ref[2].abs().amax(0)).max()
+        assert float(err2) < 1e-6
