@@ -411,10 +411,18 @@ ARENA_SHAPES = [
 ]
 
 
-def _arena_case(nat, B, T, in_f, out_f, nj, bias, seed):
+def _product_ld(in_f):
+    """Row stride the product's arena gives a Linear weight (grad_sample._row_stride): >= 64 columns -> multiple of 32,
+    narrower -> multiple of 4 (13 -> 16, 7 -> 8, 1 -> 4), so that every row can leave as 16-byte stores."""
+    from dp_timeautodiff_amd.grad_sample import _row_stride
+    return _row_stride(torch.nn.Parameter(torch.empty(1, in_f)))
+
+
+def _arena_case(nat, B, T, in_f, out_f, nj, bias, seed, ld=None):
     from oracle import opacus_ref as O
     g = torch.Generator().manual_seed(seed)
-    ld = (in_f + 31) // 32 * 32 if (in_f >= 64 and in_f % 32) else in_f
+    if ld is None:
+        ld = (in_f + 31) // 32 * 32 if (in_f >= 64 and in_f % 32) else in_f
     win = (ld * out_f + 63) // 64 * 64
     bwin = (out_f + 63) // 64 * 64
     row = 64 + nj * (win + bwin) + 64
@@ -462,6 +470,23 @@ def _arena_case(nat, B, T, in_f, out_f, nj, bias, seed):
 @pytest.mark.parametrize("bias", [True, False])
 def test_linear_grad_sample_arena_layout(nat, B, T, in_f, out_f, nj, bias):
     _arena_case(nat, B, T, in_f, out_f, nj, bias, seed=B * 1000 + T)
+
+
+# narrow layers at the row stride the PRODUCT's arena gives them (the cases above keep in < 64 unpadded, the
+# arena pads to 4 floats and relies on exact zeros in [in, ld_w): K7 and the all-reduce read those columns)
+NARROW_SHAPES = [
+    # (B, T, in, out, n_jobs)
+    (64, 24, 13, 200, 2), (50, 24, 7, 200, 1), (9, 48, 1, 125, 2), (12, 24, 33, 130, 1), (5, 48, 8, 250, 1),
+    (4096, 48, 7, 250, 1), (33, 256, 13, 512, 1), (7, 24, 62, 7, 1), (20, 40, 5, 33, 3),
+]
+
+
+@pytest.mark.parametrize("B,T,in_f,out_f,nj", NARROW_SHAPES)
+@pytest.mark.parametrize("bias", [True, False])
+def test_linear_grad_sample_narrow_rows_at_the_arena_stride(nat, B, T, in_f, out_f, nj, bias):
+    ld = _product_ld(in_f)
+    assert ld % 4 == 0 and in_f <= ld < in_f + 4
+    _arena_case(nat, B, T, in_f, out_f, nj, bias, seed=B + 7 * T + in_f, ld=ld)  # asserts zero padding, untouched neighbours
 
 
 def test_linear_grad_sample_arena_layout_many_items_is_deterministic(nat):
@@ -522,6 +547,8 @@ MULTI_LAYERS = [
     (24, 128, 13, True), (24, 200, 7, True), (24, 200, 13, False), (1, 130, 33, True), (31, 300, 260, True),
     (48, 512, 97, True), (24, 32, 128, True), (7, 64, 300, False), (24, 400, 200, True), (24, 400, 200, True),
     (24, 400, 200, True), (24, 400, 200, True), (12, 160, 40, True),
+    # narrow inputs at the arena's padded stride (13 -> 16, 7 -> 8, 1 -> 4, 33 -> 36): dead column groups, zero padding
+    (24, 13, 200, True), (24, 7, 200, True), (24, 1, 125, False), (24, 33, 40, True),
 ]
 
 
@@ -534,7 +561,7 @@ def test_linear_grad_sample_multi_equals_single_launches(nat, monkeypatch, B, ma
     if max_jobs:  # the host wrapper cuts longer job lists into several launches
         monkeypatch.setattr(nat, "K1_MULTI_MAX_JOBS", max_jobs)
     g = torch.Generator().manual_seed(B)
-    lds = [(i + 31) // 32 * 32 if (i >= 64 and i % 32) else i for _, i, _, _ in MULTI_LAYERS]
+    lds = [_product_ld(i) for _, i, _, _ in MULTI_LAYERS]
     wins = [(ld * o + 63) // 64 * 64 for ld, (_, _, o, _) in zip(lds, MULTI_LAYERS)]
     bw = [(o + 63) // 64 * 64 for _, _, o, _ in MULTI_LAYERS]
     offs, off = [], 0
@@ -585,6 +612,9 @@ def test_linear_grad_sample_multi_equals_single_launches(nat, monkeypatch, B, ma
         if bias:
             mask[offs[k] + wins[k]:offs[k] + wins[k] + o] = False
     assert (many[:, mask.cuda()] == 3.0).all()
+    for k, (T, i, o, bias) in enumerate(MULTI_LAYERS):   # row padding [in, ld) is exact zeros in both forms
+        for buf in (one, many):
+            assert not buf[:, offs[k]:offs[k] + lds[k] * o].reshape(B, o, lds[k])[:, :, i:].any(), (k, "padding")
 
 
 def test_linear_grad_sample_multi_refuses_what_it_cannot_store(nat):
