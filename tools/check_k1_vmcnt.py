@@ -100,6 +100,8 @@ def check_private(name, lines, lo=120, hi=167):
             continue
         if op == "s_waitcnt" and "vmcnt" in rest and not in_asm:
             errors.append(f"{name}:{ln}: compiler-inserted {code}")
+        if op.startswith("scratch_"):
+            errors.append(f"{name}:{ln}: spill `{code}` (a vector-memory instruction the hand-counted waits do not know)")
         if vm is not None and (op.startswith("buffer_") or op.startswith("global_") or op.startswith("flat_") or op.startswith("scratch_")):
             vm += 1
         if not in_asm:
@@ -119,7 +121,7 @@ def main():
                        check=True, stderr=subprocess.DEVNULL)
     kernels, cur, name = {}, None, None
     for ln, raw in enumerate(open(path), 1):
-        m = re.match(r"^(_Z\w*linear_gs_(?:split|ws)_kernel\w*):", raw)
+        m = re.match(r"^(_Z\w*linear_gs_(?:split|wsl?)_kernel\w*):", raw)
         if m:
             name, cur = m.group(1), []
             kernels[name] = cur
@@ -130,10 +132,10 @@ def main():
                 cur = None
     bad = 0
     for name, lines in kernels.items():
-        if "ws_kernel" in name:
-            per, errors = check_private(name, lines)
-            ws = re.search(r"ws_kernelILi(\d+)E", name)
-            print(f"ws<{ws.group(1)}>: vector-memory instructions in the text between hand-counted waits: {per}, "
+        if "ws_kernel" in name or "wsl_kernel" in name:
+            per, errors = check_private(name, lines, lo=152 if "wsl_kernel" in name else 120)
+            ws = re.search(r"(wsl?)_kernelILi(\d+)E", name)
+            print(f"{ws.group(1)}<{ws.group(2)}>: vector-memory instructions in the text between hand-counted waits: {per}, "
                   f"{len(errors)} problem(s)")
             for e in errors[:12]:
                 print("   ", e)

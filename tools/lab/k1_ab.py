@@ -20,6 +20,7 @@ SHAPES = {
     "cfg1": [(24, 400, 200, 6), (24, 208, 208, 1)],
     "lab": [(48, 512, 512, 1), (24, 512, 512, 1)],
     "cfg5": [(256, 512, 512, 1), (256, 1024, 512, 1)],
+    "cfg5big": [(256, 2048, 2048, 1), (256, 1024, 512, 6)],   # run with --B 2048 (one physical chunk): 34 / 25 GB arenas
 }
 
 

@@ -20,17 +20,19 @@ for i in range(4):
     rc = f(A.data_ptr(), G.data_ptr(), arena.data_ptr(), arena.data_ptr() + 4 * win, part.data_ptr(), part.stride(0), 0, B, T, in_f, out_f, row, ld, float(B), st)
     assert rc == 0, rc
 torch.cuda.synchronize()
-n = 64 * 8 * 9
+NW = int(os.environ.get('NWAVES_WG', '8'))
+n = 64 * NW * 9
 host = (ctypes.c_ulonglong * n)()
 lib.dpk_lab_read_stamps.argtypes = [c_void_p, c_int]
 assert lib.dpk_lab_read_stamps(host, n) == 0
-a = np.array(host[:], dtype=np.float64).reshape(64, 8, 9)
-NWV = int(os.environ.get('NWAVES', '8'))
+a = np.array(host[:], dtype=np.float64).reshape(64, NW, 9)
+NWV = int(os.environ.get('NWAVES', str(NW)))
 a = a[:, :NWV]
 names = sys.argv[6].split(",") if len(sys.argv) > 6 else [f"p{i}" for i in range(8)]
 items = a[..., 8]
-tot = a[..., :8].sum(-1)
+tot = a[..., :7].sum(-1)
 print(f"items per WG: {items.mean():.1f}; cycles per item per wave: {(tot / items).mean():.0f}")
 for w in range(NWV):
     print(f"wave {w}: " + "  ".join(f"{names[i]}={a[:, w, i].sum() / items[:, w].sum():7.0f}" for i in range(8)))
+print(f"100 MHz ticks per item: {(a[..., 7] / items).mean():.1f}  -> core clock {(tot / a[..., 7]).mean() * 0.1:.2f} GHz if s_memtime counts core cycles")
 print("all   : " + "  ".join(f"{names[i]}={a[..., i].sum() / items.sum():7.0f}" for i in range(8)))
