@@ -1181,14 +1181,7 @@ DPK_WS_QUAD(s1q2, 152, 153, 154, 155)
 DPK_WS_QUAD(s1q3, 156, 157, 158, 159)
 DPK_WS_QUAD(s1q4, 160, 161, 162, 163)
 DPK_WS_QUAD(s1q5, 164, 165, 166, 167)
-// linear_gs_wsl_kernel: one pair per set and wave, in v152-v167 (the compiler allocates 152 there)
-DPK_WS_QUAD(l0q0, 152, 153, 154, 155)
-DPK_WS_QUAD(l0q1, 156, 157, 158, 159)
-DPK_WS_QUAD(l1q0, 160, 161, 162, 163)
-DPK_WS_QUAD(l1q1, 164, 165, 166, 167)
 #undef DPK_WS_QUAD
-// (the attribute counts a unified-file kernel's registers in pairs: 76 = 152 registers for the compiler)
-#define WL_COMPILER_VGPRS 76
 template <int SET>
 __device__ __forceinline__ void ws_load_set(const u32x4 rs, unsigned off, unsigned rowb) {
     // quad 2k / 2k+1: steps 2*hq and 2*hq + 1 of step pair hq = (ptid >> 5) + 8k
@@ -1211,17 +1204,6 @@ __device__ __forceinline__ void ws_read_set(f32x4 (&r)[3][2]) {
         r[0][0] = ws_rd_s1q0(); r[0][1] = ws_rd_s1q1(); r[1][0] = ws_rd_s1q2();
         r[1][1] = ws_rd_s1q3(); r[2][0] = ws_rd_s1q4(); r[2][1] = ws_rd_s1q5();
     }
-}
-// linear_gs_wsl_kernel's pair of a set: two 16-byte rows (offsets off, off + rowb) under one descriptor
-template <int SET>
-__device__ __forceinline__ void wl_load_pair(const u32x4 rs, unsigned off, unsigned rowb) {
-    if constexpr (SET == 0) { ws_ld_l0q0(rs, off); ws_ld_l0q1(rs, off + rowb); }
-    if constexpr (SET == 1) { ws_ld_l1q0(rs, off); ws_ld_l1q1(rs, off + rowb); }
-}
-template <int SET>
-__device__ __forceinline__ void wl_read_pair(f32x4 (&r)[2]) {
-    if constexpr (SET == 0) { r[0] = ws_rd_l0q0(); r[1] = ws_rd_l0q1(); }
-    if constexpr (SET == 1) { r[0] = ws_rd_l1q0(); r[1] = ws_rd_l1q1(); }
 }
 // a loader wave's vector-memory instructions per phase: 6 operand loads, then 1 store (the squared-norm slot); a set is
 // staged two phases after it was requested: the slot store of its own phase and the whole next phase are younger
@@ -1563,28 +1545,28 @@ linear_gs_ws_kernel(
     }
 }
 
-// ---- role-split variant for LONG sequences (T > 48: cfg5's T = 256) ---------------------------------------------------
-// At T = 256 the contraction has 128 flop per output byte: K1 is bound by the matrix pipe, and linear_gs_split_kernel
-// MODE 1 kept that pipe 32 % busy (2048 x 2048, B = 2048: 32.6 ms = 135 fp32-TFLOP/s): every wave split and staged a
-// 32-step chunk of BOTH operands (~7 vector instructions per element) before it contracted it, each 128 x 128 tile
-// re-staged both of its slices, and the waves of a SIMD did the same thing at the same time.
-// Here one workgroup of 12 waves owns a 256 x 128 SUPER-TILE (two row tiles that share one A slice: 3 slices staged per
-// 2 tiles' MFMAs instead of 4) and a phase is one 16-step k-step:
-//   waves 0-3 / 4-7 (group g) contract half g of the super-tile from image buffer (phase & 1) — 6 x 4 MFMAs per wave —
-//       and stage the next k-step of THEIR OWN G rows (one 2-step x 4-column task per lane) into the other buffer;
-//   waves 8-11 stage the next k-step of the shared A columns and publish the squared-norm slots.
-// A first version had waves 8-11 stage all three slices; cycle stamps showed them to be the critical path — ~365
-// instructions of ONE in-order wave per SIMD and phase, 3900 cycles against the matrix pipe's 1536, the contractors idle
-// at the barrier for 40 % of the time — so the work is spread: every wave stages one task per phase.  The two groups run
-// the halves of a phase in opposite order (group 0: stage, contract; group 1: contract, stage), so that on each SIMD
-// one contractor's vector instructions run beside the other's MFMAs instead of both queueing for the same pipe.
-// Operand loads go to private registers two phases before they are staged, under hand-counted waits as in
-// linear_gs_ws_kernel; a contractor's wait counts 2 younger loads, plus the 17 stores of a super-tile's last phase when
-// those lie in between (uniform branch).  Accumulators persist over the T / 16 phases of a super-tile; its rows are
-// stored at the end of its last phase.  Arithmetic, k order and bias pairing are linear_gs_split_kernel's: results are
-// bit-identical.
-// the partial products (G piece p, A piece q) of one k-step in contraction order: smallest first
-struct K1Products {
+// ---- the kernel for LONG sequences (T > 48: cfg5's T = 256) --------------------------------------------------------------
+// At T = 256 the contraction has 128 flop per output byte: K1 is bound by the matrix pipe and by the vector pipe that
+// splits the operands for it.  What tools/lab/coexec.hip and cycle stamps showed on this chip:
+//   * v_mfma_f32_32x32x16_bf16 issues every 32 cycles into independent accumulators, every 44 into the same one;
+//   * beside a wave that keeps the matrix pipe full, the SIMD's other waves together get ONE vector instruction per
+//     6 - 7 cycles (about five per MFMA), and one wave alone issues one per ~5 cycles: the split's ~7 instructions per
+//     operand element are as expensive as the MFMAs they feed unless every staged element is reused widely;
+//   * an in-order wave that splits first and contracts afterwards idles one pipe, then the other.
+// linear_gs_split_kernel MODE 1 (128 x 128 tiles, every wave splits both slices of its tile, then contracts) kept the
+// matrix pipe 32 % busy (2048 x 2048, B = 2048: 32.6 ms).  A 12-wave version with 256 x 128 super-tiles (three staging
+// tasks per 48 MFMAs and SIMD: 350 vector instructions where 240 fit) reached 27.6 ms whichever waves did the staging.
+// This kernel: one workgroup of 8 waves (2 per SIMD, 256 registers each) owns a 256 x 256 SUPER-TILE — row tiles
+// 2 tm2, 2 tm2 + 1 times column tiles 2 tn2, 2 tn2 + 1 — so a phase (one 16-step k-step) stages four slice chunks for
+// sixteen tiles' MFMAs: two tasks (2 steps x 4 columns each) per lane and 48 MFMAs per wave.  Wave w owns rows
+// 32 (w & 3) .. of row tile w >> 2, all 256 columns (128 accumulator registers).  In a phase every wave
+//   contracts k-step c from image buffer c & 1 and, in the same scheduling region, splits its two tasks of k-step c + 1
+//   (its own row tile's G rows, column tile w >> 2's A columns; loaded two phases ago into private registers under a
+//   hand-counted wait) into the other buffer — four vector instructions asked for per MFMA;
+//   requests k-step c + 3; stores its rows after the super-tile's last k-step; one barrier.
+// Arithmetic, k order and bias pairing are linear_gs_split_kernel's: results are bit-identical.  An odd T / 16 contracts
+// one k-step of zeros (phases come in pairs so that the buffer index is the phase's parity).
+struct K1Products {   // the partial products (G piece p, A piece q) of one k-step in contraction order: smallest first
     int n;
     int p[9], q[9];
 };
@@ -1602,44 +1584,78 @@ constexpr K1Products k1_products(int terms) {
         }
     return L;
 }
+constexpr int WL_THREADS = 512;
 constexpr int WL_ROWB = 48;                 // image row: 16 steps of bf16 (32 B) + 16 B (3 chunks: odd, conflict-free)
 constexpr int WL_PS = 128 * WL_ROWB;        // piece stride
 constexpr int WL_IMG = 3 * WL_PS;           // one slice chunk as three bf16 images: 18,432 bytes
-constexpr int WL_BUF = 3 * WL_IMG;          // G half 0, G half 1, A
-constexpr int WL_LDS = 2 * WL_BUF + 2 * 2 * 8 * 128 * 4 + 2 * 4 * 4;   // + bias partials [buf][half][8][128] + red[2][4]
-constexpr int WL_STORE_VM = 17;             // vector-memory instructions of one wave's store(): 16 rows + the bias
+constexpr int WL_BUF = 4 * WL_IMG;          // G rows of row tile 0 / 1, A columns of column tile 0 / 1
+constexpr int WL_BIAS = 2 * 4 * 128;        // floats per buffer: bias partials [row tile][4-step group][feature]
+constexpr int WL_LDS = 2 * WL_BUF + 2 * WL_BIAS * 4 + 2 * 8 * 4;   // + red[column tile][wave]: 155,712 bytes
+constexpr int WL_STORE_VM = 33;             // vector-memory instructions of one wave's store(): 2 x 16 rows + the bias
+static_assert(WL_STORE_VM + 1 < 64, "vmcnt is a 6-bit counter");
 
-template <int TERMS>
-__global__ void __launch_bounds__(WS_THREADS) __attribute__((amdgpu_num_vgpr(WL_COMPILER_VGPRS)))
+// A lane's in-flight operands: a pair of G rows and a pair of A rows, in v240 .. v255 (the compiler allocates v0 .. v239:
+// the attribute's value is half the budget).  They are requested one phase (~1.5 us) before they are taken; a second set
+// for a two-phase lead does not fit beside 128 accumulators.
+#define WL_COMPILER_VGPRS 120
+#define DPK_WL_QUAD(NAME, A, B, C, D)                                                                           \
+    __device__ __forceinline__ void wl_ld_##NAME(const u32x4 rs, unsigned off) {                                \
+        asm volatile("buffer_load_dwordx4 v[" #A ":" #D "], %0, %1, 0 offen ; DPK_PRIVLOAD"                      \
+                     :                                                                                          \
+                     : "v"(off), "s"(rs)                                                                         \
+                     : "memory", "v" #A, "v" #B, "v" #C, "v" #D);                                                \
+    }                                                                                                           \
+    __device__ __forceinline__ f32x4 wl_rd_##NAME() {                                                           \
+        float a, b, c, d;                                                                                       \
+        asm volatile("v_mov_b32 %0, v" #A "\n\tv_mov_b32 %1, v" #B "\n\tv_mov_b32 %2, v" #C "\n\tv_mov_b32 %3, v" #D \
+                     : "=v"(a), "=v"(b), "=v"(c), "=v"(d)                                                        \
+                     :                                                                                          \
+                     : "memory");                                                                               \
+        return f32x4{a, b, c, d};                                                                               \
+    }                                                                                                           \
+    __device__ __forceinline__ f32x4 wl_rd_scaled_##NAME(float s) { /* the quad times s, rounded once (v_mul_f32) */ \
+        float a, b, c, d;                                                                                       \
+        asm volatile("v_mul_f32 %0, %4, v" #A "\n\tv_mul_f32 %1, %4, v" #B "\n\tv_mul_f32 %2, %4, v" #C         \
+                     "\n\tv_mul_f32 %3, %4, v" #D                                                               \
+                     : "=&v"(a), "=&v"(b), "=&v"(c), "=&v"(d)                                                    \
+                     : "v"(s)                                                                                   \
+                     : "memory");                                                                               \
+        return f32x4{a, b, c, d};                                                                               \
+    }
+DPK_WL_QUAD(g0, 240, 241, 242, 243)
+DPK_WL_QUAD(g1, 244, 245, 246, 247)
+DPK_WL_QUAD(a0, 248, 249, 250, 251)
+DPK_WL_QUAD(a1, 252, 253, 254, 255)
+#undef DPK_WL_QUAD
+
+// RAGGED: in_f or out_f is not a multiple of 4, so a lane's four columns can straddle the edge and are masked one by
+// one; otherwise a column group is inside (loaded) or outside (out-of-range offset: zeros) as a whole.
+template <int TERMS, bool RAGGED>
+__global__ void __launch_bounds__(WL_THREADS) __attribute__((amdgpu_num_vgpr(WL_COMPILER_VGPRS)))
 linear_gs_wsl_kernel(const K1Jobs jobs, float* __restrict__ normsq_part, int64_t part_stride, int B, int T, int in_f,
                      int out_f, int64_t gs_stride, int ld_w, int ld_g, float g_scale, int tiles_m, int tiles_n) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_b[];
-    float* sBias = reinterpret_cast<float*>(smem_b + 2 * WL_BUF);   // [2 buffers][2 halves][8 step pairs][128]
-    float* red = sBias + 2 * 2 * 8 * 128;                           // [2 halves][4 waves]
+    float* sBias = reinterpret_cast<float*>(smem_b + 2 * WL_BUF);   // [2 buffers][2 row tiles][4 groups][128]
+    float* red = sBias + 2 * WL_BIAS;                               // [2 column tiles][8 waves]
 
     const int xcd = blockIdx.x & 7;
     const unsigned rank = blockIdx.x >> 3;
     const unsigned nbx = gridDim.x >> 3;
     const unsigned nsx = (unsigned)((B - xcd + 7) / 8);
-    const int tiles_m2 = (tiles_m + 1) >> 1;                        // pairs of row tiles
-    const unsigned per_sample = (unsigned)(tiles_m2 * tiles_n), per_job = nsx * per_sample;
+    const int tiles_m2 = (tiles_m + 1) >> 1, tiles_n2 = (tiles_n + 1) >> 1;
+    const unsigned per_sample = (unsigned)(tiles_m2 * tiles_n2), per_job = nsx * per_sample;
     const unsigned total = per_job * (unsigned)jobs.n;              // super-tiles of this XCD
     if (rank >= total) return;                                      // uniform
     const int ntile = (int)((total - rank + nbx - 1) / nbx);        // super-tiles of this workgroup
-    // phases (16-step k-steps) per super-tile, made even (>= 4): a phase's buffer and register set are then compile-time
-    // constants of the loop body, which holds two phases; an odd T / 16 contracts one k-step of zeros (rows beyond T)
-    const int nch = (((T + 15) >> 4) + 1) & ~1;
-    const int P = ntile * nch + 1;                                  // + one phase to publish the last squared norms
+    const int nch = (((T + 15) >> 4) + 1) & ~1;                     // phases per super-tile: even, >= 4
 
     struct Tile {
-        int job, s, tm2, tn;
+        int job, s, tm2, tn2;
         unsigned it;
-        const float* X;   // the sample's rows of the operand this role stages (G for contractors, A for loaders)
+        const float* Gs;   // the sample's G rows and A rows (wave-uniform: scalar registers)
+        const float* As;
+        int slot0;
     };
-    const int tid = threadIdx.x;
-    const int lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const bool is_loader = wave >= 8;
     auto locate = [&](unsigned it) {   // once per super-tile (every nch phases)
         Tile x;
         x.it = it;
@@ -1648,170 +1664,184 @@ linear_gs_wsl_kernel(const K1Jobs jobs, float* __restrict__ normsq_part, int64_t
         unsigned r = u - (unsigned)x.job * per_job;
         x.s = (int)(r / per_sample);
         r -= (unsigned)x.s * per_sample;
-        x.tm2 = (int)(r / (unsigned)tiles_n);
-        x.tn = (int)(r - (unsigned)x.tm2 * (unsigned)tiles_n);
+        x.tm2 = (int)(r / (unsigned)tiles_n2);
+        x.tn2 = (int)(r - (unsigned)x.tm2 * (unsigned)tiles_n2);
         const int64_t b = x.s * 8 + xcd;
-        x.X = is_loader ? jobs.A[x.job] + b * T * in_f : jobs.G[x.job] + b * T * ld_g;
+        x.Gs = jobs.G[x.job] + b * T * ld_g;
+        x.As = jobs.A[x.job] + b * T * in_f;
+        x.slot0 = jobs.slot0[x.job];
         return x;
     };
 
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int l31 = lane & 31;
     const int lh = lane >> 5;
-    // a role's staging tasks: lane l of wave w of the role: column group pcg = (l & 7) + 8 w, step pair phq = (l >> 3) & 7
-    // (conflict-free LDS writes; a load instruction covers whole 128-byte lines)
-    const int rt = wave < 8 ? (tid & 255) : tid - WS_PROD0;
-    const int pcg = (rt & 7) + 8 * (rt >> 6), phq = (rt >> 3) & 7;
+    const int h = wave >> 2, mr = wave & 3;   // this wave's row tile (and the column tile whose A it stages), MFMA row block
+    // staging tasks: lane l of wave w: column group pcg = (l & 7) + 8 (w & 3), step pair phq = (l >> 3) & 7 of row tile /
+    // column tile h (conflict-free LDS writes; a load instruction covers whole 128-byte lines)
+    const int pcg = (lane & 7) + 8 * mr, phq = (lane >> 3) & 7;
 
-    // a pair of rows into private register set `set` / out of it (uniform branches around the literal register names)
-    auto load_pair = [](int set, const u32x4 rs, unsigned off, unsigned rowb) {
-        if (set) wl_load_pair<1>(rs, off, rowb);
-        else wl_load_pair<0>(rs, off, rowb);
+    // k-step c of super-tile x into the private registers: steps 16c + 2 phq (+1); G columns (2 tm2 + h) 128 + 4 pcg ..,
+    // A columns (2 tn2 + h) 128 + 4 pcg ..  Rows at or past T, and a super-tile past the last, lie beyond the descriptor.
+    auto request_g = [&](const Tile& x, int c) {
+        const u32x4 rsG = rsrc_words(x.Gs, x.it < total ? ((int64_t)(T - 1) * ld_g + out_f) * 4 : 0);
+        const int colg = (2 * x.tm2 + h) * 128 + pcg * 4;
+        const unsigned og = colg < out_f ? (unsigned)((16 * c + 2 * phq) * ld_g + colg) * 4u : OOB;
+        wl_ld_g0(rsG, og);
+        wl_ld_g1(rsG, og + (unsigned)ld_g * 4u);
     };
-    auto read_pair = [](int set, f32x4 (&r)[2]) {
-        if (set) wl_read_pair<1>(r);
-        else wl_read_pair<0>(r);
+    auto request_a = [&](const Tile& x, int c) {
+        const u32x4 rsA = rsrc_words(x.As, x.it < total ? (int64_t)T * in_f * 4 : 0);
+        const int cola = (2 * x.tn2 + h) * 128 + pcg * 4;
+        const unsigned oa = cola < in_f ? (unsigned)((16 * c + 2 * phq) * in_f + cola) * 4u : OOB;
+        wl_ld_a0(rsA, oa);
+        wl_ld_a1(rsA, oa + (unsigned)in_f * 4u);
     };
-    // one task: two steps (t0, t0 + 1) x four columns of slice `k` of buffer pb -> three bf16 images (+ bias partial for G)
-    auto stage_task = [&](const f32x4 (&r)[2], int k, int left, float scale, bool isG, int pb) {
-        if (DPK_K1_ABL & 4) return;
-        const f32x4 v0 = scale4_rn(mask4(r[0], left), scale), v1 = scale4_rn(mask4(r[1], left), scale);
-        if (isG) *reinterpret_cast<f32x4*>(sBias + ((pb * 2 + k) * 8 + phq) * 128 + pcg * 4) = add4_rn(v0, v1);
-        // column 4*pcg+e of the tile -> position e*32 + pcg (slot pcg of MFMA block e); step pair phq = bytes 4*phq..
-        unsigned char* dst = smem_b + pb * WL_BUF + k * WL_IMG + pcg * WL_ROWB + phq * 4;
-        // Breadth first over the four columns: an in-order wave issues a dependent vector instruction only when its
-        // predecessor's result is back, and the split of ONE column pair is a chain of 11 (column after column, as the
-        // compiler orders it to save registers, a task took 1100 cycles for ~105 instructions).  The fences keep the levels.
-        float x0[4], x1[4];
-        unsigned w[3][4];
-        if (DPK_K1_ABL & 16) {   // lab: the LDS writes without the split
+    auto request = [&](const Tile& x, int c) {
+        request_g(x, c);
+        request_a(x, c);
+    };
+    auto take = [&](f32x4 (&rg)[2], f32x4 (&ra)[2]) {
+        rg[0] = wl_rd_g0();
+        rg[1] = wl_rd_g1();
+        ra[0] = wl_rd_a0();
+        ra[1] = wl_rd_a1();
+    };
+    // the three bf16 pieces of a task's 2 steps x 4 columns (v0: step t0, v1: step t0 + 1), a word per column and piece
+    auto split_pair = [](float x0, float x1, unsigned& w0, unsigned& w1, unsigned& w2) {   // one column, steps t0, t0 + 1
+        w0 = pack_bf16_first(x0, x1);
+        x0 = rest_lo(x0, w0);
+        x1 = rest_hi(x1, w0);
+        w1 = pack_bf16_rn(x0, x1);
+        x0 = rest_lo(x0, w1);
+        x1 = rest_hi(x1, w1);
+        w2 = pack_bf16_rn(x0, x1);
+    };
+    auto split = [&](const f32x4& v0, const f32x4& v1, unsigned (&w)[3][4]) {
 #pragma unroll
-            for (int e = 0; e < 4; ++e)
-#pragma unroll
-                for (int p = 0; p < 3; ++p)
-                    *reinterpret_cast<unsigned*>(dst + e * 32 * WL_ROWB + p * WL_PS) = __builtin_bit_cast(unsigned, p ? v1[e] : v0[e]);
-            return;
-        }
-#pragma unroll
-        for (int e = 0; e < 4; ++e) w[0][e] = pack_bf16_first(v0[e], v1[e]);
-        __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            x0[e] = rest_lo(v0[e], w[0][e]);
-            x1[e] = rest_hi(v1[e], w[0][e]);
-        }
-        __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-        for (int e = 0; e < 4; ++e) w[1][e] = pack_bf16_rn(x0[e], x1[e]);
-        __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            x0[e] = rest_lo(x0[e], w[1][e]);
-            x1[e] = rest_hi(x1[e], w[1][e]);
-        }
-        __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-        for (int e = 0; e < 4; ++e) w[2][e] = pack_bf16_rn(x0[e], x1[e]);
-        __builtin_amdgcn_sched_barrier(0);
-        if ((DPK_K1_ABL & 8) && T != 12345) return;   // lab: the split without its LDS writes
+        for (int e = 0; e < 4; ++e) split_pair(v0[e], v1[e], w[0][e], w[1][e], w[2][e]);
+    };
+    // column 4*pcg+e of the tile -> position e*32 + pcg (slot pcg of MFMA block e); step pair phq = bytes 4*phq..
+    auto write_images = [&](int slice, int pn, const unsigned (&w)[3][4]) {
+        unsigned char* dst = smem_b + pn * WL_BUF + slice * WL_IMG + pcg * WL_ROWB + phq * 4;
 #pragma unroll
         for (int e = 0; e < 4; ++e)
 #pragma unroll
             for (int p = 0; p < 3; ++p) *reinterpret_cast<unsigned*>(dst + e * 32 * WL_ROWB + p * WL_PS) = w[p][e];
     };
+    // bias partial of a G task: the lane's two steps plus those of the lane 8 up (the other step pair of the 4-step
+    // group), written by the lower lane: (g[4q] + g[4q+1]) + (g[4q+2] + g[4q+3]), as linear_gs_split_kernel pairs them
+    auto write_bias = [&](int pn, const f32x4& b4) {
+        f32x4 s4;
+        // (__builtin_amdgcn_update_dpp here came out as ONE v_mov_b32_dpp whose result served all four columns)
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+            asm volatile("s_nop 1\n\tv_add_f32_dpp %0, %1, %1 row_ror:8 row_mask:0xf bank_mask:0xf" : "=v"(s4[e]) : "v"(b4[e]));
+        if ((phq & 1) == 0) *reinterpret_cast<f32x4*>(sBias + pn * WL_BIAS + (h * 4 + (phq >> 1)) * 128 + pcg * 4) = s4;
+    };
+
 #ifdef DPK_K1_STAMPS
     unsigned long long st_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, st_last = __builtin_amdgcn_s_memtime();
     const unsigned long long rt0 = __builtin_amdgcn_s_memrealtime();
 #endif
+    f32x16 acc[8];
+    float bsum = 0.f;
 
-    if (wave < 8) {
-        // ================================ contractors ================================
-        const int g = wave >> 2, mr = wave & 3;   // half g of the super-tile: row tile 2*tm2 + g
-        f32x16 acc[4];
-        float bsum = 0.f;
-        // One phase's arithmetic as ONE scheduling region: the split of this wave's task for k-step c + 1 (from the
-        // registers r, ~85 vector instructions) in the shadow of k-step c's 24 MFMAs, four vector instructions per MFMA.
-        // An in-order wave that splits first and contracts afterwards leaves the matrix pipe idle while it splits and its
-        // vector pipe idle while it contracts, and its SIMD partner, doing the same, cannot fill more than half of that.
-        // All LDS reads (buffer pb) come before all LDS writes (buffer pb ^ 1) in program order, so nothing but register
-        // dependences ties the two instruction streams together.
-        auto split_and_contract = [&](const f32x4 (&r)[2], int left, int pb) {
-            constexpr K1Products PL = k1_products(TERMS);
-            const unsigned char* buf = smem_b + pb * WL_BUF;
-            const unsigned char* pg = buf + g * WL_IMG + (mr * 32 + l31) * WL_ROWB + lh * 16;
-            const unsigned char* pa = buf + 2 * WL_IMG + l31 * WL_ROWB + lh * 16;
-            bf16x8 gv[3], av[2][3];
+    // The two halves of a phase.  contract(): k-step c's 48 MFMAs from buffer pb, column blocks j and j + 4 (the two
+    // column tiles) alternating, so that consecutive MFMAs go to different accumulators and ONE wave keeps the matrix
+    // pipe full (32 cycles per MFMA; six in a row into one accumulator run at 44 and leave gaps nobody else can use);
+    // the next pair's A pieces are read while a pair's 12 MFMAs run.  split_tasks(): the lane's two tasks of k-step
+    // c + 1 into buffer pb ^ 1 (~240 vector and LDS instructions).  The waves of row tile 0 contract, then split; their
+    // SIMD partners (row tile 1) split, then contract: each half takes ~1500 cycles, one wave's vector instructions
+    // run beside the other's MFMAs.  (Finer interleaving — a column block's MFMAs, then a column pair's split — made
+    // every vector instruction cost ~6 cycles instead of ~3.5 and ran slower; so did both partners in the same order.)
+    auto contract = [&](int pb) {
+        constexpr K1Products PL = k1_products(TERMS);
+        const unsigned char* buf = smem_b + pb * WL_BUF;
+        const unsigned char* pg = buf + h * WL_IMG + (mr * 32 + l31) * WL_ROWB + lh * 16;
+        const unsigned char* pa = buf + 2 * WL_IMG + l31 * WL_ROWB + lh * 16;
+        bf16x8 gv[3], av[2][2][3];
 #pragma unroll
-            for (int p = 0; p < 3; ++p) gv[p] = *reinterpret_cast<const bf16x8*>(pg + p * WL_PS);
-            auto load_a = [&](bf16x8 (&d)[3], int j) {
+        for (int p = 0; p < 3; ++p) gv[p] = *reinterpret_cast<const bf16x8*>(pg + p * WL_PS);
+        auto load_a = [&](bf16x8 (&d)[2][3], int jp) {   // column block jp of column tile 0 and of column tile 1
 #pragma unroll
-                for (int q = 0; q < 3; ++q) d[q] = *reinterpret_cast<const bf16x8*>(pa + q * WL_PS + j * 32 * WL_ROWB);
-            };
-            load_a(av[0], 0);
-            // the split (stage_task's arithmetic)
-            const f32x4 v0 = scale4_rn(mask4(r[0], left), g_scale), v1 = scale4_rn(mask4(r[1], left), g_scale);
-            const f32x4 b4 = add4_rn(v0, v1);
-            float x0[4], x1[4];
-            unsigned w[3][4];
+            for (int t = 0; t < 2; ++t)
 #pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                w[0][e] = pack_bf16_first(v0[e], v1[e]);
-                x0[e] = rest_lo(v0[e], w[0][e]);
-                x1[e] = rest_hi(v1[e], w[0][e]);
-                w[1][e] = pack_bf16_rn(x0[e], x1[e]);
-                x0[e] = rest_lo(x0[e], w[1][e]);
-                x1[e] = rest_hi(x1[e], w[1][e]);
-                w[2][e] = pack_bf16_rn(x0[e], x1[e]);
-            }
-            // the contraction: one column block at a time, its A pieces read while the previous block's MFMAs run
+                for (int q = 0; q < 3; ++q)
+                    d[t][q] = *reinterpret_cast<const bf16x8*>(pa + t * WL_IMG + q * WL_PS + jp * 32 * WL_ROWB);
+        };
+        // this k-step's bias partials (feature 4*l31 + mr of row tile h; the four 4-step groups in t order)
+        float bp[4];
+        {
+            const float* bq = sBias + pb * WL_BIAS + h * 4 * 128 + 4 * l31 + mr;
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                if (j < 3) load_a(av[(j + 1) & 1], j + 1);
+            for (int q = 0; q < 4; ++q) bp[q] = bq[q * 128];
+        }
+        load_a(av[0], 0);
 #pragma unroll
-                for (int k = 0; k < PL.n; ++k)
+        for (int jp = 0; jp < 4; ++jp) {
+            if (jp < 3) load_a(av[(jp + 1) & 1], jp + 1);
+#pragma unroll
+            for (int k = 0; k < PL.n; ++k)
+#pragma unroll
+                for (int t = 0; t < 2; ++t)
                     if (!(DPK_K1_ABL & 2))
-                        acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(gv[PL.p[k]], av[j & 1][PL.q[k]], acc[j], 0, 0, 0);
-            }
-            // the task's images and bias partial into the other buffer
-            const int pn = pb ^ 1;
-            *reinterpret_cast<f32x4*>(sBias + ((pn * 2 + g) * 8 + phq) * 128 + pcg * 4) = b4;
-            unsigned char* dst = smem_b + pn * WL_BUF + g * WL_IMG + pcg * WL_ROWB + phq * 4;
+                        acc[jp + 4 * t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(gv[PL.p[k]], av[jp & 1][t][PL.q[k]],
+                                                                                  acc[jp + 4 * t], 0, 0, 0);
+        }
 #pragma unroll
-            for (int e = 0; e < 4; ++e)
+        for (int q = 0; q < 4; ++q) bsum = add_rn(bsum, bp[q]);   // (lanes >= 32 add the same values; only lanes < 32 store)
+    };
+    // (the next k-step's loads go out in two pairs, each after the task that frees its registers: four at once at the
+    // top of the half, from all the waves of the workgroup at the same time, cost the issuing wave ~800 cycles)
+    auto split_tasks = [&](const Tile& xr, int cr, int left_g, int left_a, int pn) {
+        f32x4 g0, g1, ra[2];
+        if (RAGGED) {
+            g0 = scale4_rn(mask4(wl_rd_g0(), left_g), g_scale);
+            g1 = scale4_rn(mask4(wl_rd_g1(), left_g), g_scale);
+        } else {
+            g0 = wl_rd_scaled_g0(g_scale);
+            g1 = wl_rd_scaled_g1(g_scale);
+        }
+        request_g(xr, cr);
+        if (!(DPK_K1_ABL & 4)) {
+            unsigned w[3][4];
+            split(g0, g1, w);
+            write_images(h, pn, w);
+            write_bias(pn, add4_rn(g0, g1));
+        }
+        ra[0] = wl_rd_a0();
+        ra[1] = wl_rd_a1();
+        request_a(xr, cr);
+        if (!(DPK_K1_ABL & 4)) {
+            unsigned w[3][4];
+            if (RAGGED) split(mask4(ra[0], left_a), mask4(ra[1], left_a), w);
+            else split(ra[0], ra[1], w);
+            write_images(2 + h, pn, w);
+        }
+    };
+    auto store = [&](const Tile& x) {   // WL_STORE_VM vector-memory instructions on every path
+        const int tm = 2 * x.tm2 + h;
+        const int m0 = tm * 128;
+        const int64_t b = x.s * 8 + xcd;
+        const bool live = tm < tiles_m;
+        const auto rsW = make_rsrc(jobs.W[x.job] + b * gs_stride, live ? (int64_t)out_f * ld_w * 4 : 0);
+        const unsigned row_bytes = (unsigned)ld_w * 4u;
+        const float* GSb = jobs.Bi[x.job];
+        const bool has_bias = live && GSb != nullptr && x.tn2 == 0;
+        const auto rsB = make_rsrc(GSb + b * gs_stride, has_bias ? (int64_t)out_f * 4 : 0);
+        const int f = m0 + 4 * l31 + mr;
 #pragma unroll
-                for (int p = 0; p < 3; ++p) *reinterpret_cast<unsigned*>(dst + e * 32 * WL_ROWB + p * WL_PS) = w[p][e];
-            // the order asked of the scheduler: operand reads, the head of the split while they land, then per MFMA
-            // four vector instructions (and the next block's three reads early in each block), the LDS writes last
-            __builtin_amdgcn_sched_group_barrier(0x100, 6, 0);
-            __builtin_amdgcn_sched_group_barrier(0x002, 10, 0);
-#pragma unroll
-            for (int m = 0; m < 4 * PL.n; ++m) {
-                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-                if (m < 3 * PL.n && m % PL.n < 3) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
-                __builtin_amdgcn_sched_group_barrier(0x002, 4, 0);
-            }
-            __builtin_amdgcn_sched_group_barrier(0x200, 7, 0);
-        };
-        auto bias_sum = [&](int pb) {
-            if (lh == 0) {  // bias: feature 4*l31 + mr, this k-step's four 4-step groups in t order
-                const float* bp = sBias + (pb * 2 + g) * 8 * 128 + 4 * l31 + mr;
-#pragma unroll
-                for (int q = 0; q < 4; ++q) bsum = add_rn(bsum, add_rn(bp[(2 * q) * 128], bp[(2 * q + 1) * 128]));
-            }
-        };
-        auto store = [&](const Tile& x) {   // WL_STORE_VM vector-memory instructions on every path
-            const int tm = 2 * x.tm2 + g;
-            const int m0 = tm * 128, n0 = x.tn * 128;
-            const int64_t b = x.s * 8 + xcd;
-            const bool live = tm < tiles_m;
-            const auto rsW = make_rsrc(jobs.W[x.job] + b * gs_stride, live ? (int64_t)out_f * ld_w * 4 : 0);
-            const int col = n0 + 4 * l31;
-            const unsigned row_bytes = (unsigned)ld_w * 4u;
+        for (int jt = 0; jt < 2; ++jt) {
+            const int col = (2 * x.tn2 + jt) * 128 + 4 * l31;
             unsigned soff = col < ld_w ? (unsigned)((m0 + mr + 16 * lh) * ld_w + col) * 4u : OOB;
             if (DPK_K1_ABL & 1) soff = OOB;
             float sq = 0.f;
 #pragma unroll
             for (int q = 0; q < 16; ++q) {
-                const f32x4 v = {acc[0][q], acc[1][q], acc[2][q], acc[3][q]};
+                const f32x4 v = {acc[4 * jt + 0][q], acc[4 * jt + 1][q], acc[4 * jt + 2][q], acc[4 * jt + 3][q]};
                 __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), rsW, soff, 0, DPK_K1_STORE_AUX);
                 soff += ((q & 3) == 3 ? 20u : 4u) * row_bytes;  // slots 0 1 2 3 8 9 10 11 ... -> rows 4*slot
                 sq = __builtin_fmaf(v[0], v[0], sq);
@@ -1819,150 +1849,114 @@ linear_gs_wsl_kernel(const K1Jobs jobs, float* __restrict__ normsq_part, int64_t
                 sq = __builtin_fmaf(v[2], v[2], sq);
                 sq = __builtin_fmaf(v[3], v[3], sq);
             }
-            const float* GSb = jobs.Bi[x.job];
-            const bool has_bias = live && GSb != nullptr && x.tn == 0;
-            const auto rsB = make_rsrc(GSb + b * gs_stride, has_bias ? (int64_t)out_f * 4 : 0);
-            const int f = m0 + 4 * l31 + mr;
-            __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, bsum), rsB,
-                                                  lh == 0 ? (unsigned)f * 4u : OOB, 0, 0);
-            if (has_bias && lh == 0 && f < out_f) sq = __builtin_fmaf(bsum, bsum, sq);
-            const float tot = wave_sum(sq);
-            if (lane == 0) red[g * 4 + mr] = tot;
-            asm volatile("" ::: "memory");
-        };
-        // this group's G rows of k-step c of super-tile x: steps 16c + 2 phq (+1), columns (2 tm2 + g) 128 + 4 pcg ..
-        auto request_g = [&](int set, const Tile& x, int c) {
-            const int colg = (2 * x.tm2 + g) * 128 + pcg * 4;
-            const u32x4 rsG = rsrc_words(x.X, x.it < total ? ((int64_t)(T - 1) * ld_g + out_f) * 4 : 0);
-            // rows at or past T lie beyond the descriptor: zeros
-            load_pair(set, rsG, colg < out_f ? (unsigned)((16 * c + 2 * phq) * ld_g + colg) * 4u : OOB,
-                      (unsigned)ld_g * 4u);
-        };
-        auto stage_g = [&](int set, int tm2, int pb) {
-            f32x4 r[2];
-            read_pair(set, r);
-            stage_task(r, g, out_f - ((2 * tm2 + g) * 128 + pcg * 4), g_scale, true, pb);
-        };
-        auto wait_g = [](bool stores_between) {  // the pair requested two phases ago: 2 younger loads, maybe a store()
-            if (stores_between)
-                asm volatile("s_waitcnt vmcnt(%0) ; DPK_GWAIT" ::"n"(2 + WL_STORE_VM) : "memory");
-            else
-                asm volatile("s_waitcnt vmcnt(2) ; DPK_GWAIT" ::: "memory");
-        };
-        // Phase c of a super-tile (buffer c & 1: nch is even): contract k-step c; split k-step c + 1 (requested two phases
-        // ago: set and buffer (c + 1) & 1) and request k-step c + 3 into that set.
-        Tile cur = locate(rank), nxt = locate(rank + nbx);
-        // prologue: k-steps 0, 1, 2 of the first super-tile requested (sets 0, 1, 0); k-step 0 staged
-        request_g(0, cur, 0);
-        request_g(1, cur, 1);
-        asm volatile("s_waitcnt vmcnt(2) ; DPK_GWAIT" ::: "memory");
-        stage_g(0, cur.tm2, 0);
-        request_g(0, cur, 2);
-        lds_only_barrier();
-        for (int tl = 0; tl < ntile; ++tl) {
-#pragma unroll
-            for (int j = 0; j < 4; ++j)
-#pragma unroll
-                for (int q = 0; q < 16; ++q) acc[j][q] = 0.f;
-            bsum = 0.f;
-            for (int c = 0; c < nch; ++c) {
-                const int pb = c & 1;
-                const bool last = c == nch - 1;
-                // younger than the awaited pair: [store of c-2] request of c-1 [store of c-1]
-                wait_g(tl > 0 && c < 2);
-                STAMP(0);
-                f32x4 r[2];
-                read_pair(pb ^ 1, r);
-                split_and_contract(r, out_f - ((2 * (last ? nxt.tm2 : cur.tm2) + g) * 128 + pcg * 4), pb);
-                STAMP(1);
-                bias_sum(pb);
-                if (c + 3 < nch) request_g(pb ^ 1, cur, c + 3);
-                else request_g(pb ^ 1, nxt, c + 3 - nch);   // past the last super-tile: an empty descriptor, zeros
-                STAMP(3);
-                if (last) store(cur);
-                STAMP(4);
-                lds_only_barrier();
-                STAMP(2);
+            if (jt == 0) {
+                __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, bsum), rsB,
+                                                      lh == 0 ? (unsigned)f * 4u : OOB, 0, 0);
+                if (has_bias && lh == 0 && f < out_f) sq = __builtin_fmaf(bsum, bsum, sq);
             }
-            cur = nxt;
-            nxt = locate(cur.it + nbx);
+            const float tot = wave_sum(sq);
+            if (lane == 0) red[jt * 8 + wave] = tot;
         }
-        lds_only_barrier();  // the publishing phase
-#ifdef DPK_K1_STAMPS
-        st_acc[7] = __builtin_amdgcn_s_memrealtime() - rt0;
-        if (blockIdx.x < 64 && lane == 0) {
-            for (int i = 0; i < 8; ++i) dpk_stamps[(blockIdx.x * 12 + wave) * 9 + i] = st_acc[i];
-            dpk_stamps[(blockIdx.x * 12 + wave) * 9 + 8] = P - 1;
-        }
-#endif
-        return;
-    }
-
-    // =================================== loaders ===================================
-    // Per phase the next k-step of the A slice (128 columns x 16 steps: one task per lane) and the squared-norm slots of
-    // the super-tile stored in the previous phase.  Hand-counted stream: 2 loads + 1 store per phase.
-#ifdef DPK_K1_WSL_PRIO
-    __builtin_amdgcn_s_setprio(DPK_K1_WSL_PRIO);
-#endif
-    auto request_a = [&](int set, const Tile& x, int c) {
-        const int cola = x.tn * 128 + pcg * 4;
-        const u32x4 rsA = rsrc_words(x.X, x.it < total ? (int64_t)T * in_f * 4 : 0);
-        load_pair(set, rsA, cola < in_f ? (unsigned)((16 * c + 2 * phq) * in_f + cola) * 4u : OOB, (unsigned)in_f * 4u);
-    };
-    auto stage_a = [&](int set, int tn, int pb) {
-        f32x4 r[2];
-        read_pair(set, r);
-        stage_task(r, 2, in_f - (tn * 128 + pcg * 4), 1.0f, false, pb);
-    };
-    auto publish = [&](const Tile& x, bool stored) {  // squared norms of a stored super-tile's halves: lanes 0 and 1
-        const int h = rt & 1;
-        const float tot = ((red[h * 4 + 0] + red[h * 4 + 1]) + red[h * 4 + 2]) + red[h * 4 + 3];
-        const int64_t b = x.s * 8 + xcd;
-        const int tm = 2 * x.tm2 + h;
-        const bool go = stored && x.it < total;
-        const auto rsP = make_rsrc(normsq_part + b * part_stride, go ? (int64_t)part_stride * 4 : 0);
-        __builtin_amdgcn_raw_buffer_store_b32(  // ONE store instruction per wave and phase on every path
-            __builtin_bit_cast(unsigned, tot), rsP,
-            (go && rt < 2 && tm < tiles_m) ? (unsigned)(jobs.slot0[x.job] + tm * tiles_n + x.tn) * 4u : OOB, 0, 0);
         asm volatile("" ::: "memory");
     };
-    auto wait_younger = [](auto n) { asm volatile("s_waitcnt vmcnt(%0) ; DPK_PRIVWAIT" ::"n"(decltype(n)::value) : "memory"); };
-    Tile cur = locate(rank), nxt = locate(rank + nbx);
-    request_a(0, cur, 0);
-    request_a(1, cur, 1);
-    wait_younger(std::integral_constant<int, 2>{});   // k-step 0 has landed
-    stage_a(0, cur.tn, 0);
-    request_a(0, cur, 2);
-    publish(cur, false);   // stand-ins for a phase's slot store: the first waits then count as every later one
-    publish(cur, false);
-    lds_only_barrier();
-    Tile prev = cur;       // the super-tile before `cur`: its rows were stored in its last phase
-    for (int tl = 0; tl <= ntile; ++tl) {
-        const int nc = tl < ntile ? nch : 1;   // after the last super-tile: the phase that publishes its squared norms
-        for (int c = 0; c < nc; ++c) {
+    // the four squared-norm slots of a stored super-tile: lanes 0 .. 3 of wave 0; ONE store instruction per wave and call
+    auto publish = [&](const Tile& x, bool stored) {
+        const int hh = (lane >> 1) & 1, jt = lane & 1;
+        const float* rp = red + jt * 8 + hh * 4;
+        const float tot = ((rp[0] + rp[1]) + rp[2]) + rp[3];
+        const int64_t b = x.s * 8 + xcd;
+        const int tm = 2 * x.tm2 + hh, tn = 2 * x.tn2 + jt;
+        const bool go = stored && x.it < total;
+        const auto rsP = make_rsrc(normsq_part + b * part_stride, go ? (int64_t)part_stride * 4 : 0);
+        __builtin_amdgcn_raw_buffer_store_b32(
+            __builtin_bit_cast(unsigned, tot), rsP,
+            (go && tid < 4 && tm < tiles_m && tn < tiles_n) ? (unsigned)(x.slot0 + tm * tiles_n + tn) * 4u : OOB, 0, 0);
+        asm volatile("" ::: "memory");
+    };
+    // the pairs requested in the previous phase; younger: nothing, or (first phase of a later super-tile) the previous
+    // super-tile's rows and its slot store
+    auto wait_pairs = [](bool stores_between) {
+        if (stores_between)
+            asm volatile("s_waitcnt vmcnt(%0) ; DPK_GWAIT" ::"n"(WL_STORE_VM + 1) : "memory");
+        else
+            asm volatile("s_waitcnt vmcnt(0) ; DPK_GWAIT" ::: "memory");
+    };
+
+    Tile cur = locate(rank), nxt = locate(rank + nbx), prev = cur;
+    {   // prologue: k-step 0 of the first super-tile staged into buffer 0, k-step 1 requested
+        request(cur, 0);
+        asm volatile("s_waitcnt vmcnt(0) ; DPK_GWAIT" ::: "memory");
+        f32x4 rg[2], ra[2];
+        take(rg, ra);
+        request(cur, 1);
+        const int left_g = out_f - ((2 * cur.tm2 + h) * 128 + pcg * 4), left_a = in_f - ((2 * cur.tn2 + h) * 128 + pcg * 4);
+        const f32x4 g0 = scale4_rn(mask4(rg[0], left_g), g_scale), g1 = scale4_rn(mask4(rg[1], left_g), g_scale);
+        unsigned wg[3][4], wa[3][4];
+        split(g0, g1, wg);
+        split(mask4(ra[0], left_a), mask4(ra[1], left_a), wa);
+        write_bias(0, add4_rn(g0, g1));
+        write_images(h, 0, wg);
+        write_images(2 + h, 0, wa);
+        lds_only_barrier();
+    }
+    // Phase c of a super-tile (buffer c & 1).  A wave's vector-memory stream: [slot store of the previous super-tile, c = 0] |
+    // wait | 4 loads | [33 stores after the last k-step].
+    auto run = [&](auto order) {
+    constexpr int ORDER = decltype(order)::value;
+    for (int tl = 0; tl < ntile; ++tl) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j)
+#pragma unroll
+            for (int q = 0; q < 16; ++q) acc[j][q] = 0.f;
+        bsum = 0.f;
+        for (int c = 0; c < nch; ++c) {
             const int pb = c & 1;
             const bool last = c == nch - 1;
-            // younger than the awaited pair: slot store of c-2, request and slot store of c-1
-            wait_younger(std::integral_constant<int, 4>{});
-            STAMP(0);
-            stage_a(pb ^ 1, last ? nxt.tn : cur.tn, pb ^ 1);
-            STAMP(1);
-            if (c + 3 < nch) request_a(pb ^ 1, cur, c + 3);
-            else request_a(pb ^ 1, nxt, c + 3 - nch);
-            publish(prev, c == 0 && tl > 0);
-            STAMP(2);
-            lds_only_barrier();
+            const int tm2n = last ? nxt.tm2 : cur.tm2, tn2n = last ? nxt.tn2 : cur.tn2;   // k-step c + 1's super-tile
+            const int left_g = out_f - ((2 * tm2n + h) * 128 + pcg * 4), left_a = in_f - ((2 * tn2n + h) * 128 + pcg * 4);
+            if (c == 0 && tl > 0) publish(prev, true);
+            if (ORDER == 0) {
+                contract(pb);
+                __builtin_amdgcn_sched_barrier(0);
+                STAMP(0);
+            }
+            wait_pairs(c == 0 && tl > 0);
             STAMP(3);
+#ifdef DPK_K1_WSL_PRIO
+            __builtin_amdgcn_s_setprio(DPK_K1_WSL_PRIO);       // the splitting wave ahead of its partner's MFMAs
+#endif
+            // k-step c + 1 out of the private registers, k-step c + 2 requested into them (past the last super-tile: an
+            // empty descriptor, zeros)
+            if (c + 2 < nch) split_tasks(cur, c + 2, left_g, left_a, pb ^ 1);
+            else split_tasks(nxt, c + 2 - nch, left_g, left_a, pb ^ 1);
+            STAMP(6);
+#ifdef DPK_K1_WSL_PRIO
+            __builtin_amdgcn_s_setprio(0);
+#endif
+            if (ORDER == 1) {
+                __builtin_amdgcn_sched_barrier(0);
+                STAMP(0);
+                contract(pb);
+            }
+            STAMP(1);
+            if (last) store(cur);
+            STAMP(4);
+            lds_only_barrier();
+            STAMP(2);
         }
         prev = cur;
         cur = nxt;
         nxt = locate(cur.it + nbx);
     }
+    };
+    if (h == 0) run(std::integral_constant<int, 0>{});
+    else run(std::integral_constant<int, 1>{});
+    publish(prev, true);
 #ifdef DPK_K1_STAMPS
     st_acc[7] = __builtin_amdgcn_s_memrealtime() - rt0;
     if (blockIdx.x < 64 && lane == 0) {
         for (int i = 0; i < 8; ++i) dpk_stamps[(blockIdx.x * 12 + wave) * 9 + i] = st_acc[i];
-        dpk_stamps[(blockIdx.x * 12 + wave) * 9 + 8] = P;
+        dpk_stamps[(blockIdx.x * 12 + wave) * 9 + 8] = ntile * nch;
     }
 #endif
 }
@@ -2106,17 +2100,18 @@ int k1_launch(const float* const* A, const float* const* G, float* const* GSw, f
             // workgroup takes whole groups (no more workgroups than groups); otherwise it takes tiles
             const int kmode = T > PERSIST_MAX_T ? 1 : T > SPLIT_TC ? 2 : 0;
             if (kmode == 1 && k1_knobs().ws) {
-                // long sequences: role-split kernel over 256 x 128 super-tiles, one 16-step k-step per phase
-                const int64_t supers = ((int64_t)(B + 7) / 8) * 8 * ((tiles_m + 1) / 2) * slot_cols * n_jobs;
+                // long sequences: 8-wave kernel over 256 x 256 super-tiles, one 16-step k-step per phase
+                const int64_t supers = ((int64_t)(B + 7) / 8) * 8 * ((tiles_m + 1) / 2) * ((slot_cols + 1) / 2) * n_jobs;
                 int64_t want = dpk_cu_count();
                 if (want > supers) want = supers;
                 const dim3 pgrid((unsigned)((want + 7) / 8 * 8));
+                const bool ragged = (in_f % 4) != 0 || (out_f % 4) != 0;
 #define DPK_K1_WSL_GO(TERMSV)                                                                                     \
     do {                                                                                                          \
-        auto kfn = linear_gs_wsl_kernel<TERMSV>;                                                                  \
+        auto kfn = ragged ? linear_gs_wsl_kernel<TERMSV, true> : linear_gs_wsl_kernel<TERMSV, false>;             \
         hipError_t e_ = hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, WL_LDS); \
         if (e_ != hipSuccess) return (int)e_;                                                                     \
-        hipLaunchKernelGGL(kfn, pgrid, dim3(WS_THREADS), WL_LDS, s, jobs, normsq_part, part_stride, B, T, in_f,   \
+        hipLaunchKernelGGL(kfn, pgrid, dim3(WL_THREADS), WL_LDS, s, jobs, normsq_part, part_stride, B, T, in_f,   \
                            out_f, gs_stride, ld_w, ld_g, g_scale, tiles_m, slot_cols);                            \
     } while (0)
                 if (mode == 6) DPK_K1_WSL_GO(6);

@@ -133,7 +133,7 @@ def main():
     bad = 0
     for name, lines in kernels.items():
         if "ws_kernel" in name or "wsl_kernel" in name:
-            per, errors = check_private(name, lines, lo=152 if "wsl_kernel" in name else 120)
+            per, errors = check_private(name, lines, lo=240 if "wsl_kernel" in name else 120, hi=255 if "wsl_kernel" in name else 167)
             ws = re.search(r"(wsl?)_kernelILi(\d+)E", name)
             print(f"{ws.group(1)}<{ws.group(2)}>: vector-memory instructions in the text between hand-counted waits: {per}, "
                   f"{len(errors)} problem(s)")
