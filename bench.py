@@ -364,12 +364,14 @@ def run_config(cfg, ctx, args, steps, warmup, batch=None, want_hot=True):
     T_seq = max(workloads.CONFIGS[p.name]["T"] for p in parts)
     split = T_seq > 32 and os.environ.get("DPK_K1_MFMA", "") != "f32"
     role_split = split and T_seq <= 48 and os.environ.get("DPK_K1_WS", "") != "0"
+    long_seq = split and T_seq > 48 and os.environ.get("DPK_K1_WS", "") != "0"
     mfma_peak = MFMA_BF16_PEAK_TFLOPS / K1_SPLIT_TERMS if split else MFMA_F32_PEAK_TFLOPS
     ridge = mfma_peak * 1e12 / (HBM_PEAK_GBS * 1e9)
     ai = B * flops / k1_bytes
     traffic = pmc_traffic(cfg, B, parts)
     roof = {"bound": "hbm" if ai < ridge else "mfma",
             "kernel": ("linear_gs_ws_kernel (>= 3 row tiles) / linear_gs_split_kernel" if role_split else
+                       "linear_gs_wsl_kernel (T > 48: 256 x 256 super-tiles)" if long_seq else
                        "linear_gs_split_kernel" if split else "linear_gs_persist_wide_kernel") + " / linear_gs_kernel "
                       "(K1: per-sample-gradient contraction, every Linear layer of one step)",
             "arithmetic": (f"fp32 in/out, fp32 accumulate; products = {K1_SPLIT_TERMS} of the 9 exact partial products of a "

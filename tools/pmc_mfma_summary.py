@@ -58,7 +58,7 @@ def derive(rows):
         c, us = r["counters"], r["mean_us"]
         busy, gui = c.get("SQ_VALU_MFMA_BUSY_CYCLES", 0.0), c.get("GRBM_GUI_ACTIVE", 0.0)
         bf16 = busy > 0 and c.get("SQ_INSTS_VALU_MFMA_MOPS_F32", 0.0) == 0
-        m = re.match(r"linear_gs_split_kernel<(\d+)", k)
+        m = re.match(r"linear_gs_(?:split|wsl?)_kernel<(\d+)", k)
         terms = int(m.group(1)) if (m and bf16) else 1
         r["pipe"] = "bf16" if bf16 else ("f32" if busy > 0 else "-")
         r["clock_GHz"] = gui / 8 / us / 1e3 if us and gui else None
