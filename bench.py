@@ -370,7 +370,7 @@ def run_config(cfg, ctx, args, steps, warmup, batch=None, want_hot=True):
     ai = B * flops / k1_bytes
     traffic = pmc_traffic(cfg, B, parts)
     roof = {"bound": "hbm" if ai < ridge else "mfma",
-            "kernel": ("linear_gs_ws_kernel (>= 3 row tiles) / linear_gs_split_kernel" if role_split else
+            "kernel": ("linear_gs_ws_kernel (role-split, 32 < T <= 48)" if role_split else
                        "linear_gs_wsl_kernel (T > 48: 256 x 256 super-tiles)" if long_seq else
                        "linear_gs_split_kernel" if split else "linear_gs_persist_wide_kernel") + " / linear_gs_kernel "
                       "(K1: per-sample-gradient contraction, every Linear layer of one step)",

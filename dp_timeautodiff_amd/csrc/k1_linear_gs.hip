@@ -2120,10 +2120,11 @@ int k1_launch(const float* const* A, const float* const* G, float* const* GSw, f
 #undef DPK_K1_WSL_GO
                 return dpk_launch_status();
             }
-            if (kmode == 2 && (tiles_m >= 3 || slot_cols >= 3) && k1_knobs().ws) {
+            if (kmode == 2 && k1_knobs().ws) {
                 // role-split kernel: one workgroup of 12 waves per CU (loaders + two contractor groups).  A tile group =
                 // the row tiles of a column tile (A resident) if there are at least 3, else the column tiles of a row
-                // tile (G resident)
+                // tile (G resident; a large layer has in > 128: at least 2).  Even at 2 x 2 tiles, where every second
+                // tile costs an extra phase, it beats the split kernel (250 -> 250, B = 4096: 326 -> 270 us)
                 const bool swap = tiles_m < 3;
                 int64_t want = dpk_cu_count();
                 const int64_t groups = ((int64_t)(B + 7) / 8) * 8 * (swap ? tiles_m : slot_cols) * n_jobs;

@@ -78,7 +78,7 @@ int dpk_linear_grad_sample(const float* A, const float* G, float* GSw, float* GS
  * default is the fastest measured.  No counterpart in Opacus: its einsum has one arithmetic.
  *   arithmetic  -1 default (fp32 matrix instruction up to 32 steps, 6 bf16 partial products beyond) | 0 fp32 matrix
  *               instruction wherever it exists (T <= 48) | 6 | 8 | 9 partial products per fp32 product | -2 unchanged
- *   role_split  1 (default): the round-3 kernels — at 32 < T <= 48 (>= 3 row or column tiles) separate loader and
+ *   role_split  1 (default): the round-3 kernels — at 32 < T <= 48 separate loader and
  *               contractor waves, at T > 48 256 x 256 super-tiles with split and contraction halves — both
  *               bit-identical to the round-2 split kernel, which 0 puts back | -1 default | -2 unchanged
  * Initial values: environment variables DPK_K1_MFMA = f32 | split6 | split8 | split9 and DPK_K1_WS = 0, read once at

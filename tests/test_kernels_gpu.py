@@ -642,7 +642,7 @@ def test_linear_grad_sample_random_shapes(nat):
 
 
 ROLE_SPLIT_CASES = [
-    # (B, T, in, out, n_jobs, ld_g_extra)  — 32 < T <= 48 with >= 3 row or column tiles: linear_gs_ws_kernel
+    # (B, T, in, out, n_jobs, ld_g_extra)  — 32 < T <= 48: linear_gs_ws_kernel
     (37, 48, 250, 1000, 1, 0),     # the denoiser's ih/hh shape; B not a multiple of 8; ragged last row / column tile
     (16, 48, 500, 1000, 1, 0),
     (9, 33, 300, 385, 1, 0),       # T just above 32: steps 33..47 of the k-step padding are zeros; 4 row tiles, last of 1 row
@@ -651,6 +651,7 @@ ROLE_SPLIT_CASES = [
     (19, 48, 1000, 250, 1, 0),     # fewer than 3 row tiles: the G-resident form (tile group = column tiles of a row tile)
     (70, 40, 400, 130, 2, 0),      # the same with a one-row-tile-and-a-bit layer, two jobs, T < 48
     (300, 48, 640, 128, 1, 0),     # G-resident, ONE row tile, more groups than workgroups
+    (23, 48, 250, 250, 1, 0),      # 2 x 2 tiles: groups of two, a group change after every second tile
     # T > 48: linear_gs_wsl_kernel (256 x 128 super-tiles, one 16-step k-step per phase) against MODE 1
     (9, 256, 256, 256, 1, 0),      # the long-sequence VAE's T; one super-tile of two live halves per column tile
     (11, 80, 200, 300, 1, 0),      # 3 row tiles: the last super-tile has one live half; ragged rows and columns
