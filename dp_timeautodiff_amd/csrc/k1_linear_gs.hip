@@ -1949,8 +1949,14 @@ linear_gs_wsl_kernel(const K1Jobs jobs, float* __restrict__ normsq_part, int64_t
         nxt = locate(cur.it + nbx);
     }
     };
+#if defined(DPK_K1_WSL_LOCKSTEP) && DPK_K1_WSL_LOCKSTEP == 0
+    run(std::integral_constant<int, 0>{});
+#elif defined(DPK_K1_WSL_LOCKSTEP)
+    run(std::integral_constant<int, 1>{});
+#else
     if (h == 0) run(std::integral_constant<int, 0>{});
     else run(std::integral_constant<int, 1>{});
+#endif
     publish(prev, true);
 #ifdef DPK_K1_STAMPS
     st_acc[7] = __builtin_amdgcn_s_memrealtime() - rt0;
