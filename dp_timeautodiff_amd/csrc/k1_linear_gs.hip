@@ -1154,6 +1154,9 @@ constexpr int WS_LDS = 3 * WS_IMG + 2 * WS_NH * 128 * 4 + 2 * 4 * 4;  // A, G[2]
 // tools/check_k1_vmcnt.py (run by tests/test_build_checks.py) verifies on the ISA that nothing outside the inline
 // assembly names a private register and that no kernel with hand-counted waits spills.
 #define WS_COMPILER_VGPRS 60
+// (the clobber lists name registers above the compiler's budget on purpose: they are what makes the kernel descriptor
+// allocate them; clang's note that they are "reserved" is expected)
+#pragma clang diagnostic ignored "-Winline-asm"
 #define DPK_WS_QUAD(NAME, A, B, C, D)                                                                           \
     __device__ __forceinline__ void ws_ld_##NAME(const u32x4 rs, unsigned off) {                                \
         asm volatile("buffer_load_dwordx4 v[" #A ":" #D "], %0, %1, 0 offen ; DPK_PRIVLOAD"                      \

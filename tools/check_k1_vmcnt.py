@@ -131,6 +131,15 @@ def main():
             if "s_endpgm" in raw:
                 cur = None
     bad = 0
+    # the kernel descriptors must allocate the private registers (their clobber lists are what raises the count)
+    text = open(path).read()
+    for name in kernels:
+        if "ws_kernel" in name or "wsl_kernel" in name:
+            m = re.search(r"\.amdhsa_kernel " + re.escape(name) + r"\b.*?\.amdhsa_next_free_vgpr (\d+)", text, re.S)
+            need = 256 if "wsl_kernel" in name else 168
+            if not m or int(m.group(1)) < need:
+                print(f"{name}: descriptor allocates {m.group(1) if m else '?'} VGPRs, the private registers need {need}")
+                bad += 1
     for name, lines in kernels.items():
         if "ws_kernel" in name or "wsl_kernel" in name:
             per, errors = check_private(name, lines, lo=240 if "wsl_kernel" in name else 120, hi=255 if "wsl_kernel" in name else 167)
