@@ -1563,10 +1563,10 @@ linear_gs_ws_kernel(
 // 2 tm2, 2 tm2 + 1 times column tiles 2 tn2, 2 tn2 + 1 — so a phase (one 16-step k-step) stages four slice chunks for
 // sixteen tiles' MFMAs: two tasks (2 steps x 4 columns each) per lane and 48 MFMAs per wave.  Wave w owns rows
 // 32 (w & 3) .. of row tile w >> 2, all 256 columns (128 accumulator registers).  In a phase every wave
-//   contracts k-step c from image buffer c & 1 and, in the same scheduling region, splits its two tasks of k-step c + 1
-//   (its own row tile's G rows, column tile w >> 2's A columns; loaded two phases ago into private registers under a
-//   hand-counted wait) into the other buffer — four vector instructions asked for per MFMA;
-//   requests k-step c + 3; stores its rows after the super-tile's last k-step; one barrier.
+//   contracts k-step c from image buffer c & 1 and splits its two tasks of k-step c + 1 (its own row tile's G rows,
+//   column tile w >> 2's A columns; loaded one phase ago into private registers under a hand-counted wait) into the
+//   other buffer, in four chunks of 12 MFMAs + half a task, the SIMD partners in opposite order (see the phase body);
+//   requests k-step c + 2; stores its rows after the super-tile's last k-step; one barrier.
 // Arithmetic, k order and bias pairing are linear_gs_split_kernel's: results are bit-identical.  An odd T / 16 contracts
 // one k-step of zeros (phases come in pairs so that the buffer index is the phase's parity).
 struct K1Products {   // the partial products (G piece p, A piece q) of one k-step in contraction order: smallest first
@@ -1752,79 +1752,6 @@ linear_gs_wsl_kernel(const K1Jobs jobs, float* __restrict__ normsq_part, int64_t
     f32x16 acc[8];
     float bsum = 0.f;
 
-    // The two halves of a phase.  contract(): k-step c's 48 MFMAs from buffer pb, column blocks j and j + 4 (the two
-    // column tiles) alternating, so that consecutive MFMAs go to different accumulators and ONE wave keeps the matrix
-    // pipe full (32 cycles per MFMA; six in a row into one accumulator run at 44 and leave gaps nobody else can use);
-    // the next pair's A pieces are read while a pair's 12 MFMAs run.  split_tasks(): the lane's two tasks of k-step
-    // c + 1 into buffer pb ^ 1 (~240 vector and LDS instructions).  The waves of row tile 0 contract, then split; their
-    // SIMD partners (row tile 1) split, then contract: each half takes ~1500 cycles, one wave's vector instructions
-    // run beside the other's MFMAs.  (Finer interleaving — a column block's MFMAs, then a column pair's split — made
-    // every vector instruction cost ~6 cycles instead of ~3.5 and ran slower; so did both partners in the same order.)
-    auto contract = [&](int pb) {
-        constexpr K1Products PL = k1_products(TERMS);
-        const unsigned char* buf = smem_b + pb * WL_BUF;
-        const unsigned char* pg = buf + h * WL_IMG + (mr * 32 + l31) * WL_ROWB + lh * 16;
-        const unsigned char* pa = buf + 2 * WL_IMG + l31 * WL_ROWB + lh * 16;
-        bf16x8 gv[3], av[2][2][3];
-#pragma unroll
-        for (int p = 0; p < 3; ++p) gv[p] = *reinterpret_cast<const bf16x8*>(pg + p * WL_PS);
-        auto load_a = [&](bf16x8 (&d)[2][3], int jp) {   // column block jp of column tile 0 and of column tile 1
-#pragma unroll
-            for (int t = 0; t < 2; ++t)
-#pragma unroll
-                for (int q = 0; q < 3; ++q)
-                    d[t][q] = *reinterpret_cast<const bf16x8*>(pa + t * WL_IMG + q * WL_PS + jp * 32 * WL_ROWB);
-        };
-        // this k-step's bias partials (feature 4*l31 + mr of row tile h; the four 4-step groups in t order)
-        float bp[4];
-        {
-            const float* bq = sBias + pb * WL_BIAS + h * 4 * 128 + 4 * l31 + mr;
-#pragma unroll
-            for (int q = 0; q < 4; ++q) bp[q] = bq[q * 128];
-        }
-        load_a(av[0], 0);
-#pragma unroll
-        for (int jp = 0; jp < 4; ++jp) {
-            if (jp < 3) load_a(av[(jp + 1) & 1], jp + 1);
-#pragma unroll
-            for (int k = 0; k < PL.n; ++k)
-#pragma unroll
-                for (int t = 0; t < 2; ++t)
-                    if (!(DPK_K1_ABL & 2))
-                        acc[jp + 4 * t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(gv[PL.p[k]], av[jp & 1][t][PL.q[k]],
-                                                                                  acc[jp + 4 * t], 0, 0, 0);
-        }
-#pragma unroll
-        for (int q = 0; q < 4; ++q) bsum = add_rn(bsum, bp[q]);   // (lanes >= 32 add the same values; only lanes < 32 store)
-    };
-    // (the next k-step's loads go out in two pairs, each after the task that frees its registers: four at once at the
-    // top of the half, from all the waves of the workgroup at the same time, cost the issuing wave ~800 cycles)
-    auto split_tasks = [&](const Tile& xr, int cr, int left_g, int left_a, int pn) {
-        f32x4 g0, g1, ra[2];
-        if (RAGGED) {
-            g0 = scale4_rn(mask4(wl_rd_g0(), left_g), g_scale);
-            g1 = scale4_rn(mask4(wl_rd_g1(), left_g), g_scale);
-        } else {
-            g0 = wl_rd_scaled_g0(g_scale);
-            g1 = wl_rd_scaled_g1(g_scale);
-        }
-        request_g(xr, cr);
-        if (!(DPK_K1_ABL & 4)) {
-            unsigned w[3][4];
-            split(g0, g1, w);
-            write_images(h, pn, w);
-            write_bias(pn, add4_rn(g0, g1));
-        }
-        ra[0] = wl_rd_a0();
-        ra[1] = wl_rd_a1();
-        request_a(xr, cr);
-        if (!(DPK_K1_ABL & 4)) {
-            unsigned w[3][4];
-            if (RAGGED) split(mask4(ra[0], left_a), mask4(ra[1], left_a), w);
-            else split(ra[0], ra[1], w);
-            write_images(2 + h, pn, w);
-        }
-    };
     auto store = [&](const Tile& x) {   // WL_STORE_VM vector-memory instructions on every path
         const int tm = 2 * x.tm2 + h;
         const int m0 = tm * 128;
@@ -1918,48 +1845,116 @@ linear_gs_wsl_kernel(const K1Jobs jobs, float* __restrict__ normsq_part, int64_t
             const int tm2n = last ? nxt.tm2 : cur.tm2, tn2n = last ? nxt.tn2 : cur.tn2;   // k-step c + 1's super-tile
             const int left_g = out_f - ((2 * tm2n + h) * 128 + pcg * 4), left_a = in_f - ((2 * tn2n + h) * 128 + pcg * 4);
             if (c == 0 && tl > 0) publish(prev, true);
-            if (ORDER == 0) {
-                contract(pb);
-                __builtin_amdgcn_sched_barrier(0);
-                STAMP(0);
+            {
+                // Four chunks per phase.  c_chunk(jp): column blocks jp of the two column tiles, 12 MFMAs alternating between
+                // two accumulators (32 cycles each; six in a row into ONE accumulator run at 44 and leave gaps nobody
+                // else can use), then the next pair's A pieces read into the same registers.  s_chunk(k): half a task's
+                // split (G task columns 0-1, 2-3, A task columns 0-1, 2-3; ~60 vector instructions), the next k-step's
+                // loads issued where a task frees its private registers (four loads at once at the top of a phase, from
+                // all the waves of the workgroup, cost the issuing wave ~800 cycles).  The waves of row tile 0 contract,
+                // then split; their SIMD partners split, then contract: one wave's vector instructions run beside the
+                // other's MFMAs, and what is left un-overlapped at the end of a phase is one chunk.  (Whole halves in
+                // opposite order: 24.4 ms at 2048 x 2048 x T256 x B2048 against 23.3 in chunks; both partners in the
+                // same order, or the older wave splitting first: the same; a block's 6 MFMAs + one column pair's split
+                // with everything in one scheduling region: 26-28.)
+                constexpr K1Products PL = k1_products(TERMS);
+                const int pn = pb ^ 1;
+                const Tile& xr = (c + 2 < nch) ? cur : nxt;
+                const int cr = (c + 2 < nch) ? c + 2 : c + 2 - nch;
+                const unsigned char* buf = smem_b + pb * WL_BUF;
+                const unsigned char* pg = buf + h * WL_IMG + (mr * 32 + l31) * WL_ROWB + lh * 16;
+                const unsigned char* pa = buf + 2 * WL_IMG + l31 * WL_ROWB + lh * 16;
+                bf16x8 gv[3], av[2][3];
+#pragma unroll
+                for (int p = 0; p < 3; ++p) gv[p] = *reinterpret_cast<const bf16x8*>(pg + p * WL_PS);
+                auto load_a = [&](int jp) {
+#pragma unroll
+                    for (int t = 0; t < 2; ++t)
+#pragma unroll
+                        for (int q = 0; q < 3; ++q)
+                            av[t][q] = *reinterpret_cast<const bf16x8*>(pa + t * WL_IMG + q * WL_PS + jp * 32 * WL_ROWB);
+                };
+                float bp[4];
+                {
+                    const float* bq = sBias + pb * WL_BIAS + h * 4 * 128 + 4 * l31 + mr;
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) bp[q] = bq[q * 128];
+                }
+                load_a(0);
+                f32x4 g0, g1, a0, a1, b4;
+                unsigned wg[3][4], wa[3][4];
+                auto c_chunk = [&](int jp) {
+#pragma unroll
+                    for (int k = 0; k < PL.n; ++k)
+#pragma unroll
+                        for (int t = 0; t < 2; ++t)
+                            if (!(DPK_K1_ABL & 2))
+                                acc[jp + 4 * t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(gv[PL.p[k]], av[t][PL.q[k]],
+                                                                                          acc[jp + 4 * t], 0, 0, 0);
+                    __builtin_amdgcn_sched_barrier(0);
+                    if (jp < 3) load_a(jp + 1);   // into the same registers: the MFMAs above have read them
+                };
+                auto s_chunk = [&](int k) {
+                    if (k == 0) {
+                        wait_pairs(c == 0 && tl > 0);
+                        if (RAGGED) {
+                            g0 = scale4_rn(mask4(wl_rd_g0(), left_g), g_scale);
+                            g1 = scale4_rn(mask4(wl_rd_g1(), left_g), g_scale);
+                        } else {
+                            g0 = wl_rd_scaled_g0(g_scale);
+                            g1 = wl_rd_scaled_g1(g_scale);
+                        }
+                        request_g(xr, cr);
+                        b4 = add4_rn(g0, g1);
+                    }
+                    if (k == 2) {
+                        a0 = wl_rd_a0();
+                        a1 = wl_rd_a1();
+                        request_a(xr, cr);
+                        if (RAGGED) {
+                            a0 = mask4(a0, left_a);
+                            a1 = mask4(a1, left_a);
+                        }
+                    }
+                    if (DPK_K1_ABL & 4) return;
+#pragma unroll
+                    for (int e = 2 * (k & 1); e < 2 * (k & 1) + 2; ++e) {
+                        if (k < 2) split_pair(g0[e], g1[e], wg[0][e], wg[1][e], wg[2][e]);
+                        else split_pair(a0[e], a1[e], wa[0][e], wa[1][e], wa[2][e]);
+                    }
+                    if (k == 1) write_images(h, pn, wg);
+                    if (k == 3) write_images(2 + h, pn, wa);
+                };
+#pragma unroll
+                for (int jp = 0; jp < 4; ++jp) {
+                    if (ORDER == 0) {
+                        c_chunk(jp);
+                        __builtin_amdgcn_sched_barrier(0);
+                        s_chunk(jp);
+                    } else {
+                        s_chunk(jp);
+                        __builtin_amdgcn_sched_barrier(0);
+                        c_chunk(jp);
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+                if (!(DPK_K1_ABL & 4)) write_bias(pn, b4);
+#pragma unroll
+                for (int q = 0; q < 4; ++q) bsum = add_rn(bsum, bp[q]);
+                STAMP(1);
+                if (last) store(cur);
+                STAMP(4);
+                lds_only_barrier();
+                STAMP(2);
             }
-            wait_pairs(c == 0 && tl > 0);
-            STAMP(3);
-#ifdef DPK_K1_WSL_PRIO
-            __builtin_amdgcn_s_setprio(DPK_K1_WSL_PRIO);       // the splitting wave ahead of its partner's MFMAs
-#endif
-            // k-step c + 1 out of the private registers, k-step c + 2 requested into them (past the last super-tile: an
-            // empty descriptor, zeros)
-            if (c + 2 < nch) split_tasks(cur, c + 2, left_g, left_a, pb ^ 1);
-            else split_tasks(nxt, c + 2 - nch, left_g, left_a, pb ^ 1);
-            STAMP(6);
-#ifdef DPK_K1_WSL_PRIO
-            __builtin_amdgcn_s_setprio(0);
-#endif
-            if (ORDER == 1) {
-                __builtin_amdgcn_sched_barrier(0);
-                STAMP(0);
-                contract(pb);
-            }
-            STAMP(1);
-            if (last) store(cur);
-            STAMP(4);
-            lds_only_barrier();
-            STAMP(2);
         }
         prev = cur;
         cur = nxt;
         nxt = locate(cur.it + nbx);
     }
     };
-#if defined(DPK_K1_WSL_LOCKSTEP) && DPK_K1_WSL_LOCKSTEP == 0
-    run(std::integral_constant<int, 0>{});
-#elif defined(DPK_K1_WSL_LOCKSTEP)
-    run(std::integral_constant<int, 1>{});
-#else
     if (h == 0) run(std::integral_constant<int, 0>{});
     else run(std::integral_constant<int, 1>{});
-#endif
     publish(prev, true);
 #ifdef DPK_K1_STAMPS
     st_acc[7] = __builtin_amdgcn_s_memrealtime() - rt0;
