@@ -705,6 +705,40 @@ def test_role_split_kernel_equals_split_kernel_bit_for_bit(nat, B, T, in_f, out_
         assert float((part[:, j * slots:(j + 1) * slots].double().sum(1) / sq - 1).abs().max()) < 1e-6
 
 
+def test_round3_kernels_equal_the_split_kernel_on_random_shapes(nat):
+    """A seeded sweep over sequence lengths on both sides of 48, ragged feature counts, odd tile counts and batch sizes
+    that do not fill the XCDs: linear_gs_ws_kernel / linear_gs_wsl_kernel against linear_gs_split_kernel, bit for bit
+    (weights, bias, row padding, squared-norm slots, nothing outside the windows)."""
+    rng = np.random.default_rng(20240611)
+    for case in range(24):
+        T = int(rng.choice([33, 40, 48, 49, 64, 65, 96, 130, 200]))
+        in_f = int(rng.choice([129, 200, 250, 257, 384, 500, 513]))
+        out_f = int(rng.choice([33, 100, 128, 129, 250, 256, 300, 385]))
+        B = int(rng.integers(1, 40))
+        g = torch.Generator().manual_seed(case)
+        A = torch.randn(B, T, in_f, generator=g).cuda()
+        G = (torch.randn(B, T, out_f, generator=g) * 0.1).cuda()
+        ld = (in_f + 31) // 32 * 32 if in_f % 32 else in_f
+        win = (ld * out_f + 63) // 64 * 64
+        slots = nat.linear_slots(in_f, out_f)
+        outs = []
+        for split in (False, True):
+            nat.linear_configure(arithmetic="split6", role_split=split)
+            base = torch.full((B, win + (out_f + 63) // 64 * 64 + 64), 7.0, device="cuda")
+            part = torch.full((B, slots + 2), -1.0, device="cuda")
+            nat.linear_grad_sample(A, G, nat.FlatView(base, 0, ld * out_f), nat.FlatView(base, win, out_f), part, 0, 1.0, ld_w=ld)
+            torch.cuda.synchronize()
+            outs.append((base, part))
+        tag = f"case {case}: B={B} T={T} {in_f}->{out_f}"
+        assert torch.equal(outs[0][0], outs[1][0]), tag
+        assert torch.equal(outs[0][1], outs[1][1]), tag
+        assert float(outs[1][0][:, -64:].min()) == 7.0 and float(outs[1][1][:, -2:].max()) == -1.0, tag
+        ref = torch.einsum("bto,bti->boi", G.double(), A.double())
+        w = outs[1][0][:, :ld * out_f].reshape(B, out_f, ld)
+        assert not w[:, :, in_f:].any(), tag
+        assert float(((w[:, :, :in_f].double() - ref).abs().amax((1, 2)) / ref.abs().amax((1, 2))).max()) < 1e-6, tag
+
+
 # ---- special values through the bf16-split arithmetic (VERDICT r2 #5) ------------------------------------------------
 def _k1_run(nat, A, G, mode, role_split, g_scale=1.0):
     B, T, in_f = A.shape
